@@ -1,0 +1,153 @@
+/*
+ * sccbf.h - C ABI of the batched control-barrier-function QP safety filter
+ *           for AMD MI355X (gfx950).
+ *
+ * The reference (Safety-Critical-Control-WIRIN/sccav_cbf) is pure Python and
+ * has no FFI seam; each entry point below names the reference code whose
+ * arithmetic it replaces.  The Python classes that mirror the reference API
+ * (sccav_cbf_amd.cbf.*) and the batched torch front-end
+ * (sccav_cbf_amd.BatchedCBF) bind these symbols with ctypes.
+ *
+ * Conventions
+ *   - every data pointer is a DEVICE pointer owned by the caller
+ *     (hipMalloc / a torch tensor's data_ptr()); the library allocates nothing
+ *   - every call is asynchronous on `stream` (a hipStream_t, NULL = default
+ *     stream); the caller synchronises
+ *   - return value 0 = launched, <0 = argument / launch error
+ *     (sccbf_strerror); no exception crosses the ABI
+ *   - no global state: calls are re-entrant and thread-safe
+ *
+ * Memory layout ("T" = float for *_f32, double for *_f64; A agents, M slots)
+ *   state    T[A][4]        x, y, theta(yaw), v         one 4-vector / agent
+ *   u_ref    T[A][2]        DBM: a_ref, delta_ref       KBM: v_ref, delta_ref
+ *   obs      T[M][2][A][4]  obstacle slot m of agent a = the two 4-vectors
+ *                           obs[m][0][a][:] and obs[m][1][a][:]  (8 scalars);
+ *                           with SCCBF_FLAG_OBS_SHARED the table is T[M][2][4]
+ *                           and is broadcast to every agent
+ *   obs_type u8[M]          slot kind, shared by all agents; with
+ *                           SCCBF_FLAG_TYPE_PER_AGENT it is u8[M][A]
+ *   u_out    T[A][2]        DBM: a*, delta*             KBM: v*, delta*
+ *   status   i32[A]         SCCBF_STATUS_*
+ *   rows_out T[M][A][4]     optional (may be NULL): Lg_h[0], Lg_h[1], b, h of
+ *                           every row  Lg_h . u >= b   before the QP
+ *
+ * Obstacle slot contents (8 scalars o[0..7]) by kind
+ *   SCCBF_OBS_ELLIPSE  cx, cy, a, b, theta_o, vx, vy, -      (a, b include buffer)
+ *   SCCBF_OBS_CONE     cx, cy, theta_o, v_o, a, beta, -, -   (a includes buffer)
+ *   SCCBF_OBS_LANE     c0, c1, c2, c3, buffer, -, -, -       y = c0+c1 x+c2 x^2+c3 x^3
+ *   SCCBF_OBS_RADIAL   cx, cy, a, b, cdot_x, cdot_y, kv, -
+ *   SCCBF_OBS_EMPTY    ignored (row 0.u >= -1, always satisfied)
+ */
+#ifndef SCCBF_H_
+#define SCCBF_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SCCBF_VERSION 100 /* 0.1.0 */
+
+/* obstacle kinds: 0..2 follow Obstacle2DTypes, reference cbf/obstacles.py:51-57 */
+#define SCCBF_OBS_ELLIPSE 0
+#define SCCBF_OBS_CONE 1
+#define SCCBF_OBS_LANE 2
+#define SCCBF_OBS_RADIAL 3 /* test_scripts/radial_dynamic_obstacles.py:391-411 */
+#define SCCBF_OBS_EMPTY 255
+
+/* vehicle model */
+#define SCCBF_DYN_DBM 0 /* DBM_CBF_2DS,  reference cbf/cbf.py:112-220, u = [a, beta]  */
+#define SCCBF_DYN_KBM 1 /* KBM_VC_CBF2D, reference cbf/cbf.py:33-110,  u = [v, omega] */
+
+/* per-agent result */
+#define SCCBF_STATUS_OPTIMAL 0
+#define SCCBF_STATUS_INFEASIBLE 1 /* rows admit no u; u_out = u_ref (pass-through) */
+#define SCCBF_STATUS_NONFINITE 2  /* NaN/Inf in the inputs; u_out = u_ref */
+
+/* flags */
+#define SCCBF_FLAG_OBS_SHARED 1u     /* obs is T[M][2][4], one table for all agents */
+#define SCCBF_FLAG_TYPE_PER_AGENT 2u /* obs_type is u8[M][A] */
+#define SCCBF_FLAG_SLIP_IO 4u        /* u_ref[1] / u_out[1] are already in QP coordinates (slip
+                                        angle beta for DBM, yaw rate omega for KBM): skip the
+                                        steering transforms of reference cbf/cbf.py:175,216,75,109 */
+
+/* error codes */
+#define SCCBF_OK 0
+#define SCCBF_ERR_ARG (-1)         /* NULL pointer / negative size / bad enum */
+#define SCCBF_ERR_ROWS (-2)        /* M above SCCBF_MAX_ROWS */
+#define SCCBF_ERR_WEIGHT (-3)      /* R not symmetric positive definite */
+#define SCCBF_ERR_LAUNCH (-4)      /* hipLaunch failed */
+#define SCCBF_ERR_VARIANT (-5)     /* lanes_per_qp cannot hold M rows */
+#define SCCBF_ERR_NO_DEVICE (-6)   /* no HIP device / wrong architecture */
+
+#define SCCBF_MAX_ROWS 1024
+
+/*
+ * Filter parameters; replaces the attributes of the reference filter objects:
+ * alpha (cbf.py:130,147-148), lr/lf (150-152), L (61-62), R (154-157),
+ * ZERO_TOL (cbf/utils.py:27).
+ */
+typedef struct sccbf_params {
+    double alpha;         /* class-K gain, h_dot >= -alpha h */
+    double lr, lf;        /* DBM: CoM to rear / front axle [m] */
+    double L;             /* KBM: wheel base [m] */
+    double R[4];          /* QP weight, row-major 2x2, symmetric positive definite */
+    double zero_tol;      /* 1e-3 in the reference */
+    int32_t dynamics;     /* SCCBF_DYN_* */
+    int32_t lanes_per_qp; /* 0 = choose; 1,2,4,8,16 = register-resident rows with that
+                             many cooperating lanes per QP; 64 = one wavefront per QP,
+                             rows staged in LDS (any M <= SCCBF_MAX_ROWS) */
+    uint32_t flags;       /* SCCBF_FLAG_* */
+    int32_t reserved;
+} sccbf_params;
+
+int sccbf_version(void);
+const char* sccbf_strerror(int code);
+
+/* Writes the defaults of the reference objects: alpha 1 (cbf.py:128), R = I
+ * (cbf.py:134), zero_tol 1e-3, lr = lf = 1.45, L = 2.9
+ * (test_scripts/stanley_controller_ellipse.py:55-57), DBM, lanes_per_qp 0. */
+void sccbf_default_params(sccbf_params* p);
+
+/*
+ * One control tick for A agents: barrier value and partials of every obstacle
+ * slot, Lie derivatives, constraint rows, then the 2-input QP
+ *      min (u - u_ref)^T R (u - u_ref)   s.t.   Lg_h . u >= -(Lf_h + alpha h + dh/dt)
+ * including the steering <-> slip transforms on the way in and out.
+ * Replaces DBM_CBF_2DS.solve_cbf (reference cbf/cbf.py:166-220) /
+ * KBM_VC_CBF2D.solve_cbf (cbf.py:67-110) together with
+ * ObstacleList2D.f/dx/dy/dtheta/dv/dt (cbf/obstacles.py:879-925) and the
+ * per-obstacle formulas of Ellipse2D (183-236, 310-317), CollisionCone2D
+ * (401-502), PolyLane (607-689) and the radial time-varying ellipse
+ * (test_scripts/radial_dynamic_obstacles.py:391-411).
+ */
+int sccbf_solve_f32(const sccbf_params* p, int64_t A, int32_t M,
+                    const float* state, const float* u_ref,
+                    const float* obs, const uint8_t* obs_type,
+                    float* u_out, int32_t* status, float* rows_out,
+                    void* stream);
+int sccbf_solve_f64(const sccbf_params* p, int64_t A, int32_t M,
+                    const double* state, const double* u_ref,
+                    const double* obs, const uint8_t* obs_type,
+                    double* u_out, int32_t* status, double* rows_out,
+                    void* stream);
+
+/*
+ * The QP stage alone, on caller-supplied rows: for each agent
+ *      min (u - u_nom)^T R (u - u_nom)   s.t.   rows[m][a][0..1] . u >= rows[m][a][2]
+ * (rows is T[M][A][4], the 4th scalar is ignored; a row with a zero normal and
+ * a non-positive right-hand side is "empty").  No steering transform is applied.
+ * Replaces the cvxopt.solvers.cp call of reference cbf/cbf.py:213 (and 107).
+ */
+int sccbf_qp_f32(const sccbf_params* p, int64_t A, int32_t M,
+                 const float* rows, const float* u_nom,
+                 float* u_out, int32_t* status, void* stream);
+int sccbf_qp_f64(const sccbf_params* p, int64_t A, int32_t M,
+                 const double* rows, const double* u_nom,
+                 double* u_out, int32_t* status, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SCCBF_H_ */

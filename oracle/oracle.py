@@ -1,0 +1,165 @@
+"""ctypes front-end of the CPU oracle (oracle/cbf_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: the parity checker and the timed CPU baseline.  Only
+tests/, the smoke check and bench.py's cpu_baseline leg import this module; the
+product package never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "liboracle.so")
+
+OBS_ELLIPSE, OBS_CONE, OBS_LANE, OBS_RADIAL, OBS_EMPTY = 0, 1, 2, 3, 255
+DYN_DBM, DYN_KBM = 0, 1
+FLAG_OBS_SHARED, FLAG_TYPE_PER_AGENT, FLAG_SLIP_IO = 1, 2, 4
+
+
+class Params(C.Structure):
+    """Field-for-field the sccbf_params of include/sccbf.h."""
+    _fields_ = [("alpha", C.c_double), ("lr", C.c_double), ("lf", C.c_double), ("L", C.c_double),
+                ("R", C.c_double * 4), ("zero_tol", C.c_double), ("dynamics", C.c_int32),
+                ("lanes_per_qp", C.c_int32), ("flags", C.c_uint32), ("reserved", C.c_int32)]
+
+
+class Partials(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("h", "hx", "hy", "hth", "hv", "ht")]
+
+
+def make_params(alpha=1.0, lr=1.45, lf=1.45, L=2.9, R=(1.0, 0.0, 0.0, 1.0), zero_tol=1e-3,
+                dynamics=DYN_DBM, flags=0, lanes_per_qp=0):
+    p = Params()
+    p.alpha, p.lr, p.lf, p.L = alpha, lr, lf, L
+    R = np.asarray(R, dtype=np.float64).reshape(-1)
+    for i in range(4):
+        p.R[i] = float(R[i])
+    p.zero_tol, p.dynamics, p.flags, p.lanes_per_qp = zero_tol, dynamics, flags, lanes_per_qp
+    return p
+
+
+def build(force=False):
+    """Compile liboracle.so with the Makefile next to this file."""
+    src = os.path.join(_HERE, "cbf_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "liboracle.so"])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        L = C.CDLL(_SO)
+        dp = C.POINTER(C.c_double)
+        L.orc_solve_batch.restype = C.c_int
+        L.orc_solve_batch.argtypes = [C.POINTER(Params), C.c_int64, C.c_int32, dp, dp, dp,
+                                      C.POINTER(C.c_uint8), dp, C.POINTER(C.c_int32), dp, C.c_int]
+        L.orc_qp_batch.restype = C.c_int
+        L.orc_qp_batch.argtypes = [C.POINTER(Params), C.c_int64, C.c_int32, dp, dp, dp,
+                                   C.POINTER(C.c_int32), C.c_int]
+        L.orc_barrier.restype = C.c_int
+        L.orc_barrier.argtypes = [C.c_int, dp, dp, C.c_double, C.POINTER(Partials)]
+        L.orc_row.restype = None
+        L.orc_row.argtypes = [C.POINTER(Params), dp, C.POINTER(Partials), dp]
+        L.orc_lane_closest_x.restype = C.c_double
+        L.orc_lane_closest_x.argtypes = [dp, C.c_double, C.c_double]
+        L.orc_vehicle_step.restype = C.c_double
+        L.orc_vehicle_step.argtypes = [dp] + [C.c_double] * 6
+        L.orc_stanley.restype = C.c_double
+        L.orc_stanley.argtypes = [dp, C.c_int, dp, dp, dp, C.c_int, C.c_double, C.c_double,
+                                  C.c_double, C.POINTER(C.c_int)]
+        _lib = L
+    return _lib
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def solve_batch(params, state, u_ref, obs, obs_type, want_rows=False, incremental=False):
+    """One tick for A agents.  state (A,4), u_ref (A,2), obs (M,2,A,4) or (M,2,4) when
+    FLAG_OBS_SHARED, obs_type (M,) or (M,A) uint8.  Returns u_out (A,2), status (A,),
+    rows (M,A,4) or None."""
+    state, u_ref, obs = _f64(state), _f64(u_ref), _f64(obs)
+    obs_type = np.ascontiguousarray(obs_type, dtype=np.uint8)
+    A, M = state.shape[0], obs.shape[0]
+    assert state.shape == (A, 4) and u_ref.shape == (A, 2)
+    if params.flags & FLAG_OBS_SHARED:
+        assert obs.shape == (M, 2, 4)
+    else:
+        assert obs.shape == (M, 2, A, 4)
+    assert obs_type.shape == ((M, A) if params.flags & FLAG_TYPE_PER_AGENT else (M,))
+    u_out = np.empty((A, 2))
+    status = np.empty(A, dtype=np.int32)
+    rows = np.empty((M, A, 4)) if want_rows else None
+    rc = lib().orc_solve_batch(C.byref(params), A, M, _dp(state), _dp(u_ref), _dp(obs),
+                               obs_type.ctypes.data_as(C.POINTER(C.c_uint8)), _dp(u_out),
+                               status.ctypes.data_as(C.POINTER(C.c_int32)),
+                               _dp(rows) if want_rows else None, int(incremental))
+    if rc != 0:
+        raise ValueError("orc_solve_batch failed: %d" % rc)
+    return u_out, status, rows
+
+
+def qp_batch(params, rows, u_nom, incremental=False):
+    """QP stage alone.  rows (M,A,4) [a0,a1,b,-], u_nom (A,2) -> u (A,2), status (A,)."""
+    rows, u_nom = _f64(rows), _f64(u_nom)
+    M, A = rows.shape[0], rows.shape[1]
+    assert rows.shape == (M, A, 4) and u_nom.shape == (A, 2)
+    u_out = np.empty((A, 2))
+    status = np.empty(A, dtype=np.int32)
+    rc = lib().orc_qp_batch(C.byref(params), A, M, _dp(rows), _dp(u_nom), _dp(u_out),
+                            status.ctypes.data_as(C.POINTER(C.c_int32)), int(incremental))
+    if rc != 0:
+        raise ValueError("orc_qp_batch failed: %d" % rc)
+    return u_out, status
+
+
+def barrier(kind, s, o, zero_tol=1e-3):
+    """h and partials of one obstacle slot: returns dict h,hx,hy,hth,hv,ht."""
+    s, o8 = _f64(s), np.zeros(8)
+    o = _f64(o).reshape(-1)
+    o8[:o.size] = o
+    d = Partials()
+    lib().orc_barrier(int(kind), _dp(s), _dp(o8), zero_tol, C.byref(d))
+    return {n: getattr(d, n) for n, _ in Partials._fields_}
+
+
+def row(params, s, partials):
+    d = Partials(**partials)
+    s = _f64(s)
+    out = np.empty(3)
+    lib().orc_row(C.byref(params), _dp(s), C.byref(d), _dp(out))
+    return out
+
+
+def lane_closest_x(coeffs, px, py):
+    c = np.zeros(4)
+    cc = _f64(coeffs).reshape(-1)
+    c[:cc.size] = cc
+    return lib().orc_lane_closest_x(_dp(c), float(px), float(py))
+
+
+def vehicle_step(s, acc, delta, lr, lf, max_steer, dt):
+    """In-place bicycle step on s (4,) float64; returns beta."""
+    assert s.dtype == np.float64 and s.flags.c_contiguous
+    return lib().orc_vehicle_step(_dp(s), acc, delta, lr, lf, max_steer, dt)
+
+
+def stanley(s, cx, cy, cyaw, last_idx, axle, k, ks=0.0):
+    s, cx, cy, cyaw = _f64(s), _f64(cx), _f64(cy), _f64(cyaw)
+    idx = C.c_int(0)
+    d = lib().orc_stanley(_dp(s), cx.size, _dp(cx), _dp(cy), _dp(cyaw), int(last_idx), axle, k, ks,
+                          C.byref(idx))
+    return d, idx.value

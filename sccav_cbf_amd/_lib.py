@@ -1,0 +1,64 @@
+"""ctypes binding of libsccbf.so (the C ABI declared in include/sccbf.h).
+
+There is no CPU fallback: if the HIP library is missing, load() raises.
+"""
+import ctypes as C
+import os
+
+from ._build import LIB
+
+OBS_ELLIPSE, OBS_CONE, OBS_LANE, OBS_RADIAL, OBS_EMPTY = 0, 1, 2, 3, 255
+DYN_DBM, DYN_KBM = 0, 1
+STATUS_OPTIMAL, STATUS_INFEASIBLE, STATUS_NONFINITE = 0, 1, 2
+FLAG_OBS_SHARED, FLAG_TYPE_PER_AGENT, FLAG_SLIP_IO = 1, 2, 4
+MAX_ROWS = 1024
+
+EXPORTS = ("sccbf_version", "sccbf_strerror", "sccbf_default_params", "sccbf_solve_f32",
+           "sccbf_solve_f64", "sccbf_qp_f32", "sccbf_qp_f64")
+
+
+class Params(C.Structure):
+    """struct sccbf_params of include/sccbf.h."""
+    _fields_ = [("alpha", C.c_double), ("lr", C.c_double), ("lf", C.c_double), ("L", C.c_double),
+                ("R", C.c_double * 4), ("zero_tol", C.c_double), ("dynamics", C.c_int32),
+                ("lanes_per_qp", C.c_int32), ("flags", C.c_uint32), ("reserved", C.c_int32)]
+
+
+class SccbfError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load the HIP library; raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB):
+        raise SccbfError(
+            "libsccbf.so not found at %s: build it with `python -m sccav_cbf_amd._build` "
+            "(hipcc, gfx950). There is no CPU fallback." % LIB)
+    L = C.CDLL(LIB)
+    vp = C.c_void_p
+    L.sccbf_version.restype = C.c_int
+    L.sccbf_strerror.restype = C.c_char_p
+    L.sccbf_strerror.argtypes = [C.c_int]
+    L.sccbf_default_params.restype = None
+    L.sccbf_default_params.argtypes = [C.POINTER(Params)]
+    for name in ("sccbf_solve_f32", "sccbf_solve_f64"):
+        f = getattr(L, name)
+        f.restype = C.c_int
+        f.argtypes = [C.POINTER(Params), C.c_int64, C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp]
+    for name in ("sccbf_qp_f32", "sccbf_qp_f64"):
+        f = getattr(L, name)
+        f.restype = C.c_int
+        f.argtypes = [C.POINTER(Params), C.c_int64, C.c_int32, vp, vp, vp, vp, vp]
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise SccbfError("sccbf: %s (code %d)" % (load().sccbf_strerror(rc).decode(), rc))

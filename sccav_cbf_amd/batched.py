@@ -1,0 +1,179 @@
+"""Batched front-end of the CBF-QP safety filter: torch tensors in HBM -> C ABI -> HIP kernels.
+
+One call = one control tick for every agent of the batch (the work that the
+reference does per ego in DBM_CBF_2DS.solve_cbf, cbf/cbf.py:166-220, with the
+obstacle partials of cbf/obstacles.py).  Tensors hold device memory and the
+current stream; all arithmetic is in libsccbf.so.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import (DYN_DBM, DYN_KBM, FLAG_OBS_SHARED, FLAG_SLIP_IO, FLAG_TYPE_PER_AGENT, OBS_CONE, OBS_ELLIPSE,
+                   OBS_EMPTY, OBS_LANE, OBS_RADIAL)
+
+_DYN = {"dbm": DYN_DBM, "kbm": DYN_KBM, DYN_DBM: DYN_DBM, DYN_KBM: DYN_KBM}
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+class BatchedCBF:
+    """CBF-QP filter over a batch of A agents with M obstacle slots each.
+
+    Parameters mirror the reference filter objects: alpha (set_alpha), lr/lf or L
+    (set_model_params), R (set_qp_cost_weight); dynamics "dbm" = DBM_CBF_2DS
+    (u = [a, delta]) or "kbm" = KBM_VC_CBF2D (u = [v, delta]).
+    lanes_per_qp: 0 lets the library choose; 1/2/4/8/16 cooperating lanes per QP
+    with rows in registers; 64 = one wavefront per QP with rows in LDS.
+    """
+
+    def __init__(self, alpha=1.0, lr=1.45, lf=1.45, L=2.9, R=None, dynamics="dbm",
+                 zero_tol=1e-3, lanes_per_qp=0, slip_io=False):
+        self._lib = _lib.load()
+        self.params = _lib.Params()
+        self._lib.sccbf_default_params(C.byref(self.params))
+        self.params.alpha = float(alpha)
+        self.params.lr, self.params.lf, self.params.L = float(lr), float(lf), float(L)
+        self.params.zero_tol = float(zero_tol)
+        self.params.dynamics = _DYN[dynamics]
+        self.params.lanes_per_qp = int(lanes_per_qp)
+        # slip_io: u_ref[:,1] / u_out[:,1] are slip angles (DBM) or yaw rates (KBM) already
+        self.slip_io = bool(slip_io)
+        self.set_qp_cost_weight(np.eye(2) if R is None else R)
+
+    # -- setters with the reference's names (cbf/cbf.py:147-157)
+    def set_alpha(self, alpha=1.0):
+        self.params.alpha = float(alpha)
+
+    def set_model_params(self, lr=None, lf=None, L=None):
+        if lr is not None:
+            self.params.lr = float(lr)
+        if lf is not None:
+            self.params.lf = float(lf)
+        if L is not None:
+            self.params.L = float(L)
+
+    def set_qp_cost_weight(self, R):
+        R = np.asarray(R, dtype=np.float64)
+        if R.shape != (2, 2):
+            raise ValueError("Expected a symmetric matrix of size 2 as input.")
+        for i in range(4):
+            self.params.R[i] = float(R.reshape(-1)[i])
+
+    # -- the hot path
+    def solve(self, state, u_ref, obs, obs_type, u_out=None, status=None, rows_out=None,
+              want_rows=False):
+        """state (A,4), u_ref (A,2), obs (M,2,A,4) [or (M,2,4): one table shared by all
+        agents], obs_type uint8 (M,) [or (M,A)].  Returns (u_out (A,2), status (A,) int32)
+        and, with want_rows/rows_out, rows (M,A,4) = Lg_h0, Lg_h1, b, h.
+        Asynchronous on the current stream."""
+        if not state.is_cuda:
+            raise _lib.SccbfError("BatchedCBF.solve needs tensors on the GPU (no CPU fallback)")
+        dt = state.dtype
+        if dt not in (torch.float32, torch.float64):
+            raise TypeError("state must be float32 or float64")
+        A = state.shape[0]
+        M = obs.shape[0]
+        dev = state.device
+        flags = FLAG_SLIP_IO if self.slip_io else 0
+        if obs.dim() == 3:
+            flags |= FLAG_OBS_SHARED
+            exp_obs = (M, 2, 4)
+        else:
+            exp_obs = (M, 2, A, 4)
+        if obs_type.dim() == 2:
+            flags |= FLAG_TYPE_PER_AGENT
+            exp_ty = (M, A)
+        else:
+            exp_ty = (M,)
+        for name, t, shape, dtype in (("state", state, (A, 4), dt), ("u_ref", u_ref, (A, 2), dt),
+                                      ("obs", obs, exp_obs, dt),
+                                      ("obs_type", obs_type, exp_ty, torch.uint8)):
+            if tuple(t.shape) != shape or t.dtype != dtype or t.device != dev or not t.is_contiguous():
+                raise ValueError("%s: expected contiguous %s %s on %s, got %s %s on %s" % (
+                    name, shape, dtype, dev, tuple(t.shape), t.dtype, t.device))
+        if u_out is None:
+            u_out = torch.empty((A, 2), dtype=dt, device=dev)
+        if status is None:
+            status = torch.empty((A,), dtype=torch.int32, device=dev)
+        if want_rows and rows_out is None:
+            rows_out = torch.empty((M, A, 4), dtype=dt, device=dev)
+        for name, t, shape, dtype in (("u_out", u_out, (A, 2), dt), ("status", status, (A,), torch.int32),
+                                      ("rows_out", rows_out, (M, A, 4), dt)):
+            if t is not None and (tuple(t.shape) != shape or t.dtype != dtype or t.device != dev
+                                  or not t.is_contiguous()):
+                raise ValueError("%s: expected contiguous %s %s on %s" % (name, shape, dtype, dev))
+        self.params.flags = flags
+        fn = self._lib.sccbf_solve_f32 if dt == torch.float32 else self._lib.sccbf_solve_f64
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            rc = fn(C.byref(self.params), A, M, _ptr(state), _ptr(u_ref), _ptr(obs), _ptr(obs_type),
+                    _ptr(u_out), _ptr(status), _ptr(rows_out), C.c_void_p(stream))
+        _lib.check(rc)
+        if rows_out is not None:
+            return u_out, status, rows_out
+        return u_out, status
+
+    def solve_qp(self, rows, u_nom, u_out=None, status=None):
+        """QP stage alone: rows (M,A,4) = a0, a1, b, - with a.u >= b; u_nom (A,2)."""
+        if not rows.is_cuda:
+            raise _lib.SccbfError("BatchedCBF.solve_qp needs tensors on the GPU (no CPU fallback)")
+        dt, dev = rows.dtype, rows.device
+        M, A = rows.shape[0], rows.shape[1]
+        for name, t, shape in (("rows", rows, (M, A, 4)), ("u_nom", u_nom, (A, 2))):
+            if tuple(t.shape) != shape or t.dtype != dt or t.device != dev or not t.is_contiguous():
+                raise ValueError("%s: expected contiguous %s %s on %s" % (name, shape, dt, dev))
+        if u_out is None:
+            u_out = torch.empty((A, 2), dtype=dt, device=dev)
+        if status is None:
+            status = torch.empty((A,), dtype=torch.int32, device=dev)
+        fn = self._lib.sccbf_qp_f32 if dt == torch.float32 else self._lib.sccbf_qp_f64
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            rc = fn(C.byref(self.params), A, M, _ptr(rows), _ptr(u_nom), _ptr(u_out), _ptr(status),
+                    C.c_void_p(stream))
+        _lib.check(rc)
+        return u_out, status
+
+
+# ---------------------------------------------------------------- slot packing helpers
+def ellipse_slots(cx, cy, a, b, theta=0.0, vx=0.0, vy=0.0):
+    """Rows of 8 scalars for SCCBF_OBS_ELLIPSE (a, b already include any buffer)."""
+    return _stack8(cx, cy, a, b, theta, vx, vy, 0.0)
+
+
+def cone_slots(cx, cy, theta_o, v_o, a, beta=0.0):
+    """SCCBF_OBS_CONE slots (a already includes the buffer, reference default 1.5)."""
+    return _stack8(cx, cy, theta_o, v_o, a, beta, 0.0, 0.0)
+
+
+def lane_slots(c0, c1=0.0, c2=0.0, c3=0.0, buffer=1.5):
+    return _stack8(c0, c1, c2, c3, buffer, 0.0, 0.0, 0.0)
+
+
+def radial_slots(cx, cy, a, b, cdot_x=0.0, cdot_y=0.0, kv=1.0):
+    return _stack8(cx, cy, a, b, cdot_x, cdot_y, kv, 0.0)
+
+
+def _stack8(*cols):
+    ref = None
+    for c in cols:
+        if torch.is_tensor(c):
+            ref = c
+            break
+    if ref is None:
+        return torch.tensor([float(c) for c in cols], dtype=torch.float64)
+    out = [c if torch.is_tensor(c) else torch.full_like(ref, float(c)) for c in cols]
+    return torch.stack(out, dim=-1)
+
+
+def pack_obs(slots):
+    """(M, A, 8) per-agent slots (or (M, 8) shared) -> the ABI layout (M,2,A,4) / (M,2,4)."""
+    if slots.dim() == 2:
+        return slots.reshape(slots.shape[0], 2, 4).contiguous()
+    M, A, _ = slots.shape
+    return slots.reshape(M, A, 2, 4).permute(0, 2, 1, 3).contiguous()

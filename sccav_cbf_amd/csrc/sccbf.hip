@@ -1,0 +1,797 @@
+// sccbf.hip - batched CBF-QP safety filter for gfx950 (MI355X): HIP kernels + C ABI.
+//
+// One control tick per agent: barrier value and partials of every obstacle slot,
+// Lie derivatives -> constraint rows, then the 2-input QP.  Rows never touch HBM.
+//
+// Two kernel families share the row and QP arithmetic:
+//   k_group<T, G, RPL>  G cooperating lanes per QP (G = 1, 2, 4, 8, 16), each lane
+//                       keeps RPL rows in registers; cross-lane steps are shuffles
+//                       inside the G-lane group.  G = 1 is one thread per QP.
+//   k_wave<T, WPB>      one 64-lane wavefront per QP, rows staged in LDS, any M;
+//                       first-violated search by ballot, bounds by wave shuffles.
+//
+// The QP (reference cbf/cbf.py:182-213 hands it to cvxopt.solvers.cp) is solved
+// exactly: in w = Lc^T (u - u_nom), R = Lc Lc^T, it is the least-norm point of the
+// polygon { at_i . w >= bt_i }.  Starting from w = 0 the lowest-index violated row
+// is found; the optimum then lies on that row's line, and the 1-D problem along the
+// line bounded by the earlier rows is solved.  Rows are visited in increasing index,
+// so at most M line solves happen per QP.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <cmath>
+
+#include "sccbf.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kLaneIters = 32;     // Newton iterations for the lane closest point
+constexpr int kLaneHalvings = 30;  // step halvings per iteration
+
+template <typename T> struct VT;
+template <> struct VT<float> {
+    using v4 = float4;
+    using v2 = float2;
+};
+template <> struct VT<double> {
+    using v4 = double4;
+    using v2 = double2;
+};
+
+template <typename T> struct KArgs {
+    T alpha, lr, lf, L;
+    T l10, inv_l00, inv_l11;  // Cholesky factor of R
+    T zero_tol;
+    int dynamics;
+    unsigned flags;
+    long long A;
+    int M;
+    const T* state;
+    const T* u_ref;
+    const T* obs;   // obstacle slots, or rows (M,A,4) for the QP-only entry
+    const uint8_t* obs_type;
+    T* u_out;
+    int* status;
+    T* rows_out;
+};
+
+// ------------------------------------------------------------------ math shims
+__device__ inline void sincos_(float x, float* s, float* c) { sincosf(x, s, c); }
+__device__ inline void sincos_(double x, double* s, double* c) { sincos(x, s, c); }
+__device__ inline float sqrt_(float x) { return sqrtf(x); }
+__device__ inline double sqrt_(double x) { return sqrt(x); }
+__device__ inline float rsqrt_(float x) { return rsqrtf(x); }
+__device__ inline double rsqrt_(double x) { return 1.0 / sqrt(x); }
+__device__ inline float tan_(float x) { return tanf(x); }
+__device__ inline double tan_(double x) { return tan(x); }
+__device__ inline float atan2_(float y, float x) { return atan2f(y, x); }
+__device__ inline double atan2_(double y, double x) { return atan2(y, x); }
+__device__ inline float abs_(float x) { return fabsf(x); }
+__device__ inline double abs_(double x) { return fabs(x); }
+__device__ inline float max_(float a, float b) { return fmaxf(a, b); }
+__device__ inline double max_(double a, double b) { return fmax(a, b); }
+__device__ inline float min_(float a, float b) { return fminf(a, b); }
+__device__ inline double min_(double a, double b) { return fmin(a, b); }
+__device__ inline bool finite_(float x) { return isfinite(x); }
+__device__ inline bool finite_(double x) { return isfinite(x); }
+
+template <typename T> struct Lim;
+template <> struct Lim<float> {
+    static constexpr float eps = 1.1920929e-7f;
+    static constexpr float tiny_n2 = 1e-30f;   // squared row norm below this = zero row
+    static constexpr float viol_tol = 2e-6f;   // relative slack of the "violated" test
+    static constexpr float par_tol = 1e-6f;    // |sin| below this = parallel rows
+    static constexpr float lane_xtol = 3e-4f;
+};
+template <> struct Lim<double> {
+    static constexpr double eps = 2.220446049250313e-16;
+    static constexpr double tiny_n2 = 1e-300;
+    static constexpr double viol_tol = 1e-12;
+    static constexpr double par_tol = 1e-14;
+    static constexpr double lane_xtol = 1e-8;
+};
+
+// ------------------------------------------------------------- cross-lane helpers
+// Reductions over the G consecutive lanes of a cooperative group (G power of two <= 64).
+__device__ inline float shfl_xor_(float v, int m, int w) { return __shfl_xor(v, m, w); }
+__device__ inline int shfl_xor_(int v, int m, int w) { return __shfl_xor(v, m, w); }
+__device__ inline double shfl_xor_(double v, int m, int w) { return __shfl_xor(v, m, w); }
+__device__ inline float shfl_(float v, int l, int w) { return __shfl(v, l, w); }
+__device__ inline double shfl_(double v, int l, int w) { return __shfl(v, l, w); }
+
+template <int G, typename T> __device__ inline T group_max(T v)
+{
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) v = max_(v, shfl_xor_(v, o, G));
+    return v;
+}
+template <int G, typename T> __device__ inline T group_min(T v)
+{
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) v = min_(v, shfl_xor_(v, o, G));
+    return v;
+}
+template <int G> __device__ inline int group_imin(int v)
+{
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) {
+        int t = shfl_xor_(v, o, G);
+        v = t < v ? t : v;
+    }
+    return v;
+}
+template <int G> __device__ inline int group_or(int v)
+{
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) v |= shfl_xor_(v, o, G);
+    return v;
+}
+
+// --------------------------------------------------------------------- barriers
+template <typename T> struct Partials {
+    T h, hx, hy, hth, hv, ht;
+};
+
+// Ellipse2D, reference cbf/obstacles.py:183-236, 310-317 (dt as written: no rotation).
+template <typename T>
+__device__ inline void ellipse_(T x, T y, const T o[8], Partials<T>& r)
+{
+    T xd = x - o[0], yd = y - o[1];
+    T ia2 = T(1) / (o[2] * o[2]), ib2 = T(1) / (o[3] * o[3]);
+    T st, ct;
+    sincos_(o[4], &st, &ct);
+    T p = xd * ct + yd * st;
+    T q = -xd * st + yd * ct;
+    r.h = p * p * ia2 + q * q * ib2 - T(1);
+    r.hx = T(2) * (ct * ia2 * p - st * ib2 * q);
+    r.hy = T(2) * (st * ia2 * p + ct * ib2 * q);
+    r.hth = T(0);
+    r.hv = T(0);
+    r.ht = T(-2) * (xd * ia2 * o[5] + yd * ib2 * o[6]);
+}
+
+// Time-varying ellipse with speed margin, reference
+// test_scripts/radial_dynamic_obstacles.py:391-405.
+template <typename T>
+__device__ inline void radial_(T x, T y, T v, const T o[8], Partials<T>& r)
+{
+    T xd = x - o[0], yd = y - o[1];
+    T ia2 = T(1) / (o[2] * o[2]), ib2 = T(1) / (o[3] * o[3]);
+    T iv = T(1) / (T(1) + v);
+    r.h = xd * xd * ia2 + yd * yd * ib2 - T(1) - o[6] * v * iv;
+    r.hx = T(2) * xd * ia2;
+    r.hy = T(2) * yd * ib2;
+    r.hth = T(0);
+    r.hv = -o[6] * iv * iv;
+    r.ht = T(-2) * (xd * ia2 * o[4] + yd * ib2 * o[5]);
+}
+
+// CollisionCone2D, reference cbf/obstacles.py:468-502 (state), 401-458 (partials).
+template <typename T>
+__device__ inline void cone_(T x, T y, T th, T v, T cth, T sth, const T o[8], T eps,
+                             Partials<T>& r)
+{
+    T xd = x - o[0], yd = y - o[1];
+    T beta = o[5], a = o[4];
+    T svx = v * cth, svy = v * sth;
+    T so, co;
+    sincos_(o[2] + beta, &so, &co);
+    T ovx = o[3] * co, ovy = o[3] * so;
+    T dvx = svx - ovx, dvy = svy - ovy;
+    T d2 = xd * xd + yd * yd;
+    T dist = sqrt_(d2);
+    T vn = sqrt_(dvx * dvx + dvy * dvy);
+    T cb = eps;
+    if (dist > abs_(a)) cb = sqrt_(d2 - a * a) + eps;
+    T cos_phi = (dist > eps) ? cb / dist : T(0);
+    T c = cth, sn = sth;
+    if (beta != T(0)) sincos_(th + beta, &sn, &c);
+    T icb = T(1) / (cb + eps);
+    T cbn = cb / (vn + eps);
+    r.h = (xd * dvx + yd * dvy) + dist * vn * cos_phi;
+    r.hx = dvx + vn * xd * icb;
+    r.hy = dvy + vn * yd * icb;
+    r.hv = (xd * c + yd * sn) + (dvx * c + dvy * sn) * cbn;
+    r.hth = (-xd * svy + yd * svx) + (-dvx * svy + dvy * svx) * cbn;
+    r.ht = (-dvx * ovx - dvy * ovy) - vn * (xd * ovx + yd * ovy) * icb;
+}
+
+template <typename T> __device__ inline void poly3_(const T c[8], T x, T& f, T& df, T& ddf)
+{
+    f = c[0] + x * (c[1] + x * (c[2] + x * c[3]));
+    df = c[1] + x * (T(2) * c[2] + x * T(3) * c[3]);
+    ddf = T(2) * c[2] + T(6) * c[3] * x;
+}
+
+// Abscissa of the curve point nearest to (px, py): descent from x0 = px, Newton with
+// the true curvature, halving until the distance does not grow.  Replaces the scipy
+// Newton-CG call of PolyLane.get_shortest_distance_x, reference cbf/obstacles.py:641-679.
+template <typename T> __device__ inline T lane_closest_x_(const T c[8], T px, T py)
+{
+    T x = px;
+    for (int it = 0; it < kLaneIters; ++it) {
+        T f, df, ddf;
+        poly3_(c, x, f, df, ddf);
+        T rr = f - py;
+        T g0 = (x - px) * (x - px) + rr * rr;
+        T g1 = T(2) * (x - px) + T(2) * rr * df;
+        T g2 = T(2) * (T(1) + df * df + rr * ddf);
+        T step = (g2 > T(1e-12)) ? -g1 / g2 : -g1 / (abs_(g2) + T(1));
+        if (step == T(0)) break;
+        T xn = x + step;
+        T glim = g0 * (T(1) + T(8) * Lim<T>::eps);
+        for (int k = 0; k < kLaneHalvings; ++k) {
+            T fn, dfn, ddfn;
+            poly3_(c, xn, fn, dfn, ddfn);
+            T gn = (xn - px) * (xn - px) + (fn - py) * (fn - py);
+            if (gn <= glim) break;
+            step *= T(0.5);
+            xn = x + step;
+        }
+        x = xn;
+        if (abs_(step) <= Lim<T>::lane_xtol * (T(1) + abs_(x))) break;
+    }
+    return x;
+}
+
+// PolyLane, reference cbf/obstacles.py:620-636, 607-612, 681-689 (eta and the
+// un-squared buffer as written).
+template <typename T>
+__device__ inline void lane_(T x, T y, const T o[8], T eps, Partials<T>& r)
+{
+    T cx = lane_closest_x_(o, x, y);
+    T g, dg, ddg;
+    poly3_(o, cx, g, dg, ddg);
+    T eta = T(1) + dg * ddg + dg * dg - y * ddg;
+    if (abs_(eta) < eps) eta = eps;
+    T ie = T(2) / eta;
+    r.h = (cx - x) * (cx - x) + (g - y) * (g - y) - o[4];
+    r.hx = ie * ((x - cx) * (eta - T(1)) - (y - g) * dg);
+    r.hy = ie * (-(x - cx) * dg + (y - g) * (eta - dg * dg));
+    r.hth = T(0);
+    r.hv = T(0);
+    r.ht = T(0);
+}
+
+// Per-agent quantities every row needs.
+template <typename T> struct Ego {
+    T x, y, th, v, cth, sth;
+    T un0, un1;  // nominal input in QP coordinates
+};
+
+// One obstacle slot -> constraint row  a . u >= b  (u-space) and barrier value h.
+// DBM contraction: reference cbf/cbf.py:159-164, 200-207.  KBM: cbf/cbf.py:94-101.
+template <typename T>
+__device__ inline void slot_row_(int type, const T o[8], const Ego<T>& e, const KArgs<T>& p,
+                                 T& a0, T& a1, T& b, T& h)
+{
+    Partials<T> d;
+    switch (type) {
+    case SCCBF_OBS_ELLIPSE: ellipse_(e.x, e.y, o, d); break;
+    case SCCBF_OBS_CONE: cone_(e.x, e.y, e.th, e.v, e.cth, e.sth, o, p.zero_tol, d); break;
+    case SCCBF_OBS_LANE: lane_(e.x, e.y, o, p.zero_tol, d); break;
+    case SCCBF_OBS_RADIAL: radial_(e.x, e.y, e.v, o, d); break;
+    default:
+        a0 = T(0); a1 = T(0); b = T(-1); h = T(1);
+        return;
+    }
+    h = d.h;
+    if (p.dynamics == SCCBF_DYN_KBM) {
+        a0 = e.cth * d.hx + e.sth * d.hy;
+        a1 = d.hth;
+        b = -(p.alpha * d.h);
+    } else {
+        a0 = d.hv;
+        a1 = e.v * (-e.sth * d.hx + e.cth * d.hy) + (e.v / p.lr) * d.hth;
+        T lf_h = e.v * (e.cth * d.hx + e.sth * d.hy);
+        b = -(lf_h + p.alpha * d.h + d.ht);
+    }
+}
+
+// u-space row -> unit-normal row in w-space; zero rows keep at = 0.
+template <typename T>
+__device__ inline void to_wspace_(T a0, T a1, T b, const Ego<T>& e, const KArgs<T>& p,
+                                  T& at0, T& at1, T& bt)
+{
+    T t0 = a0 * p.inv_l00;
+    T t1 = (a1 - p.l10 * t0) * p.inv_l11;
+    T rhs = b - (a0 * e.un0 + a1 * e.un1);
+    T n2 = t0 * t0 + t1 * t1;
+    if (n2 > Lim<T>::tiny_n2) {
+        T inv = rsqrt_(n2);
+        at0 = t0 * inv;
+        at1 = t1 * inv;
+        bt = rhs * inv;
+    } else {
+        at0 = T(0);
+        at1 = T(0);
+        bt = rhs;
+    }
+}
+
+template <typename T>
+__device__ inline void load_ego_(const KArgs<T>& p, long long qp, bool qp_only, Ego<T>& e,
+                                 T& ur0, T& ur1, int& bad)
+{
+    using v4 = typename VT<T>::v4;
+    using v2 = typename VT<T>::v2;
+    const v2 ur = reinterpret_cast<const v2*>(p.u_ref)[qp];
+    ur0 = ur.x;
+    ur1 = ur.y;
+    bad = !(finite_(ur0) && finite_(ur1));
+    if (qp_only) {
+        e.x = e.y = e.th = e.v = T(0);
+        e.cth = T(1);
+        e.sth = T(0);
+        e.un0 = ur0;
+        e.un1 = ur1;
+        return;
+    }
+    const v4 s = reinterpret_cast<const v4*>(p.state)[qp];
+    e.x = s.x; e.y = s.y; e.th = s.z; e.v = s.w;
+    bad |= !(finite_(s.x) && finite_(s.y) && finite_(s.z) && finite_(s.w));
+    sincos_(e.th, &e.sth, &e.cth);
+    e.un0 = ur0;
+    if (p.flags & SCCBF_FLAG_SLIP_IO)
+        e.un1 = ur1;
+    else if (p.dynamics == SCCBF_DYN_KBM)
+        e.un1 = ur0 * tan_(ur1) / p.L;                       // reference cbf/cbf.py:75
+    else
+        e.un1 = atan2_(p.lr * tan_(ur1), p.lf + p.lr);       // reference cbf/cbf.py:175
+}
+
+template <typename T>
+__device__ inline void store_result_(const KArgs<T>& p, long long qp, bool qp_only, int st,
+                                     T w0, T w1, const Ego<T>& e, T ur0, T ur1)
+{
+    using v2 = typename VT<T>::v2;
+    v2 out;
+    if (st != SCCBF_STATUS_OPTIMAL) {
+        out.x = ur0;
+        out.y = ur1;
+    } else {
+        // u = u_nom + Lc^-T w
+        T y1 = w1 * p.inv_l11;
+        T y0 = (w0 - p.l10 * y1) * p.inv_l00;
+        T u0 = e.un0 + y0, u1 = e.un1 + y1;
+        out.x = u0;
+        if (qp_only || (p.flags & SCCBF_FLAG_SLIP_IO))
+            out.y = u1;
+        else if (p.dynamics == SCCBF_DYN_KBM)
+            out.y = atan2_(u1 * p.L, ur0);                    // reference cbf/cbf.py:109
+        else
+            out.y = atan2_((p.lf + p.lr) * tan_(u1), p.lr);   // reference cbf/cbf.py:216
+    }
+    reinterpret_cast<v2*>(p.u_out)[qp] = out;
+    p.status[qp] = st;
+}
+
+// ------------------------------------------------- G lanes per QP, rows in registers
+template <typename T, int G, int RPL, bool QP_ONLY>
+__global__ __launch_bounds__(kBlock) void k_group(const KArgs<T> p)
+{
+    using v4 = typename VT<T>::v4;
+    const long long gid = (long long)blockIdx.x * kBlock + threadIdx.x;
+    const long long qp = gid / G;
+    const int g = (int)(gid % G);
+    if (qp >= p.A) return;  // groups are lane-aligned: a whole group leaves together
+
+    const int M = p.M;
+    const bool shared = (p.flags & SCCBF_FLAG_OBS_SHARED) != 0;
+    const bool type_pa = (p.flags & SCCBF_FLAG_TYPE_PER_AGENT) != 0;
+    const v4* obs4 = reinterpret_cast<const v4*>(p.obs);
+
+    // issue every load of this lane before any arithmetic
+    v4 oa[RPL], ob[RPL];
+    int ty[RPL];
+#pragma unroll
+    for (int r = 0; r < RPL; ++r) {
+        const int m = r * G + g;
+        ty[r] = SCCBF_OBS_EMPTY;
+        oa[r] = v4{T(0), T(0), T(-1), T(0)};
+        ob[r] = v4{T(0), T(0), T(0), T(0)};
+        if (m < M) {
+            if (QP_ONLY) {
+                oa[r] = obs4[(long long)m * p.A + qp];
+                ty[r] = 0;
+            } else {
+                const long long i0 = shared ? (long long)m * 2 : (long long)m * 2 * p.A + qp;
+                oa[r] = obs4[i0];
+                ob[r] = obs4[i0 + (shared ? 1 : p.A)];
+                ty[r] = type_pa ? p.obs_type[(long long)m * p.A + qp] : p.obs_type[m];
+            }
+        }
+    }
+    Ego<T> e;
+    T ur0, ur1;
+    int bad;
+    load_ego_(p, qp, QP_ONLY, e, ur0, ur1, bad);
+
+    // rows of this lane, unit normals in w-space
+    T at0[RPL], at1[RPL], bt[RPL];
+#pragma unroll
+    for (int r = 0; r < RPL; ++r) {
+        const int m = r * G + g;
+        T a0, a1, b, h;
+        if (QP_ONLY) {
+            a0 = oa[r].x; a1 = oa[r].y; b = oa[r].z; h = T(0);
+        } else {
+            const T o[8] = {oa[r].x, oa[r].y, oa[r].z, oa[r].w, ob[r].x, ob[r].y, ob[r].z, ob[r].w};
+            slot_row_(ty[r], o, e, p, a0, a1, b, h);
+            if (p.rows_out && m < M)
+                reinterpret_cast<v4*>(p.rows_out)[(long long)m * p.A + qp] = v4{a0, a1, b, h};
+        }
+        bad |= !(finite_(a0) && finite_(a1) && finite_(b));
+        to_wspace_(a0, a1, b, e, p, at0[r], at1[r], bt[r]);
+    }
+    bad = group_or<G>(bad);
+
+    T w0 = T(0), w1 = T(0);
+    int st = bad ? SCCBF_STATUS_NONFINITE : SCCBF_STATUS_OPTIMAL;
+    int last = -1;
+    while (st == SCCBF_STATUS_OPTIMAL) {
+        // lowest-index row above `last` that the current optimum violates
+        int first = 0x7fffffff;
+#pragma unroll
+        for (int r = RPL - 1; r >= 0; --r) {
+            const int m = r * G + g;
+            const T lhs = at0[r] * w0 + at1[r] * w1;
+            const T scale = abs_(at0[r] * w0) + abs_(at1[r] * w1) + abs_(bt[r]);
+            if (m > last && lhs - bt[r] < -Lim<T>::viol_tol * scale) first = m;
+        }
+        first = group_imin<G>(first);
+        if (first == 0x7fffffff) break;
+        // fetch that row from its owner lane
+        const int rsel = first / G, owner = first % G;
+        T c0 = T(0), c1 = T(0), cb = T(0);
+#pragma unroll
+        for (int r = 0; r < RPL; ++r)
+            if (r == rsel) { c0 = at0[r]; c1 = at1[r]; cb = bt[r]; }
+        if (G > 1) {
+            c0 = shfl_(c0, owner, G);
+            c1 = shfl_(c1, owner, G);
+            cb = shfl_(cb, owner, G);
+        }
+        if (c0 == T(0) && c1 == T(0)) {  // 0 . u >= positive
+            st = SCCBF_STATUS_INFEASIBLE;
+            break;
+        }
+        // optimum on the line c . w = cb: w = p + t d, minimise |w| over the earlier rows
+        const T p0 = c0 * cb, p1 = c1 * cb;
+        const T d0 = -c1, d1 = c0;
+        T tlo = -INFINITY, thi = INFINITY;
+        int inf = 0;
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) {
+            const int m = r * G + g;
+            const T cs = at0[r] * d0 + at1[r] * d1;
+            const T ee = bt[r] - (at0[r] * p0 + at1[r] * p1);
+            const bool act = (m < first) && !(at0[r] == T(0) && at1[r] == T(0));
+            if (act) {
+                if (abs_(cs) > Lim<T>::par_tol) {
+                    const T t = ee / cs;
+                    if (cs > T(0)) tlo = max_(tlo, t);
+                    else thi = min_(thi, t);
+                } else if (ee > T(1e-6) * (abs_(bt[r]) + abs_(cb)) + Lim<T>::tiny_n2) {
+                    inf = 1;
+                }
+            }
+        }
+        tlo = group_max<G>(tlo);
+        thi = group_min<G>(thi);
+        inf = group_or<G>(inf);
+        if (inf || tlo > thi + T(1e-6) * (abs_(tlo) + abs_(thi))) {
+            st = SCCBF_STATUS_INFEASIBLE;
+            break;
+        }
+        const T t = min_(max_(T(0), tlo), thi);
+        w0 = p0 + t * d0;
+        w1 = p1 + t * d1;
+        last = first;
+    }
+    if (g == 0) store_result_(p, qp, QP_ONLY, st, w0, w1, e, ur0, ur1);
+}
+
+// ------------------------------------------ one wavefront per QP, rows staged in LDS
+template <typename T, int WPB, bool QP_ONLY>
+__global__ __launch_bounds__(WPB * 64) void k_wave(const KArgs<T> p)
+{
+    using v4 = typename VT<T>::v4;
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    const int M = p.M;
+    T* s_at0 = reinterpret_cast<T*>(smem_raw) + (size_t)wv * 3 * M;
+    T* s_at1 = s_at0 + M;
+    T* s_bt = s_at1 + M;
+
+    long long qp = (long long)blockIdx.x * WPB + wv;
+    const bool live = qp < p.A;
+    if (!live) qp = p.A - 1;  // keep the wave for the block barrier; its stores are masked
+
+    const bool shared = (p.flags & SCCBF_FLAG_OBS_SHARED) != 0;
+    const bool type_pa = (p.flags & SCCBF_FLAG_TYPE_PER_AGENT) != 0;
+    const v4* obs4 = reinterpret_cast<const v4*>(p.obs);
+
+    Ego<T> e;
+    T ur0, ur1;
+    int bad;
+    load_ego_(p, qp, QP_ONLY, e, ur0, ur1, bad);
+
+    for (int m = lane; m < M; m += 64) {
+        T a0, a1, b, h;
+        if (QP_ONLY) {
+            const v4 rw = obs4[(long long)m * p.A + qp];
+            a0 = rw.x; a1 = rw.y; b = rw.z; h = T(0);
+        } else {
+            const long long i0 = shared ? (long long)m * 2 : (long long)m * 2 * p.A + qp;
+            const v4 oa = obs4[i0];
+            const v4 ob = obs4[i0 + (shared ? 1 : p.A)];
+            const int ty = type_pa ? p.obs_type[(long long)m * p.A + qp] : p.obs_type[m];
+            const T o[8] = {oa.x, oa.y, oa.z, oa.w, ob.x, ob.y, ob.z, ob.w};
+            slot_row_(ty, o, e, p, a0, a1, b, h);
+            if (p.rows_out && live)
+                reinterpret_cast<v4*>(p.rows_out)[(long long)m * p.A + qp] = v4{a0, a1, b, h};
+        }
+        bad |= !(finite_(a0) && finite_(a1) && finite_(b));
+        T t0, t1, tb;
+        to_wspace_(a0, a1, b, e, p, t0, t1, tb);
+        s_at0[m] = t0;
+        s_at1[m] = t1;
+        s_bt[m] = tb;
+    }
+    bad = __any(bad);
+    __syncthreads();
+
+    T w0 = T(0), w1 = T(0);
+    int st = bad ? SCCBF_STATUS_NONFINITE : SCCBF_STATUS_OPTIMAL;
+    int last = -1;
+    while (st == SCCBF_STATUS_OPTIMAL) {  // wave-uniform loop
+        int first = -1;
+        for (int base = ((last + 1) / 64) * 64; base < M; base += 64) {
+            const int m = base + lane;
+            bool viol = false;
+            if (m < M && m > last) {
+                const T r0 = s_at0[m], r1 = s_at1[m], rb = s_bt[m];
+                const T lhs = r0 * w0 + r1 * w1;
+                const T scale = abs_(r0 * w0) + abs_(r1 * w1) + abs_(rb);
+                viol = lhs - rb < -Lim<T>::viol_tol * scale;
+            }
+            const unsigned long long mask = __ballot(viol);
+            if (mask) {
+                first = base + __builtin_ctzll(mask);
+                break;
+            }
+        }
+        if (first < 0) break;
+        const T c0 = s_at0[first], c1 = s_at1[first], cb = s_bt[first];  // broadcast read
+        if (c0 == T(0) && c1 == T(0)) {
+            st = SCCBF_STATUS_INFEASIBLE;
+            break;
+        }
+        const T p0 = c0 * cb, p1 = c1 * cb;
+        const T d0 = -c1, d1 = c0;
+        T tlo = -INFINITY, thi = INFINITY;
+        int inf = 0;
+        for (int m = lane; m < first; m += 64) {
+            const T r0 = s_at0[m], r1 = s_at1[m], rb = s_bt[m];
+            if (r0 == T(0) && r1 == T(0)) continue;
+            const T cs = r0 * d0 + r1 * d1;
+            const T ee = rb - (r0 * p0 + r1 * p1);
+            if (abs_(cs) > Lim<T>::par_tol) {
+                const T t = ee / cs;
+                if (cs > T(0)) tlo = max_(tlo, t);
+                else thi = min_(thi, t);
+            } else if (ee > T(1e-6) * (abs_(rb) + abs_(cb)) + Lim<T>::tiny_n2) {
+                inf = 1;
+            }
+        }
+        tlo = group_max<64>(tlo);
+        thi = group_min<64>(thi);
+        inf = __any(inf);
+        if (inf || tlo > thi + T(1e-6) * (abs_(tlo) + abs_(thi))) {
+            st = SCCBF_STATUS_INFEASIBLE;
+            break;
+        }
+        const T t = min_(max_(T(0), tlo), thi);
+        w0 = p0 + t * d0;
+        w1 = p1 + t * d1;
+        last = first;
+    }
+    if (lane == 0 && live) store_result_(p, qp, QP_ONLY, st, w0, w1, e, ur0, ur1);
+}
+
+// ------------------------------------------------------------------- host side
+template <typename T>
+int fill_args(const sccbf_params* sp, int64_t A, int32_t M, KArgs<T>& k)
+{
+    if (!sp || A < 0 || M < 0) return SCCBF_ERR_ARG;
+    if (M > SCCBF_MAX_ROWS) return SCCBF_ERR_ROWS;
+    if (sp->dynamics != SCCBF_DYN_DBM && sp->dynamics != SCCBF_DYN_KBM) return SCCBF_ERR_ARG;
+    const double r00 = sp->R[0], r01 = 0.5 * (sp->R[1] + sp->R[2]), r11 = sp->R[3];
+    if (!(r00 > 0.0) || !std::isfinite(r00) || !std::isfinite(r01) || !std::isfinite(r11))
+        return SCCBF_ERR_WEIGHT;
+    const double l00 = std::sqrt(r00), l10 = r01 / l00, t = r11 - l10 * l10;
+    if (!(t > 0.0)) return SCCBF_ERR_WEIGHT;
+    const double l11 = std::sqrt(t);
+    if (sp->dynamics == SCCBF_DYN_DBM && !(sp->lr > 0.0 && sp->lf + sp->lr > 0.0)) return SCCBF_ERR_ARG;
+    if (sp->dynamics == SCCBF_DYN_KBM && !(sp->L > 0.0)) return SCCBF_ERR_ARG;
+    k.alpha = (T)sp->alpha; k.lr = (T)sp->lr; k.lf = (T)sp->lf; k.L = (T)sp->L;
+    k.l10 = (T)l10; k.inv_l00 = (T)(1.0 / l00); k.inv_l11 = (T)(1.0 / l11);
+    k.zero_tol = (T)sp->zero_tol;
+    k.dynamics = sp->dynamics;
+    k.flags = sp->flags;
+    k.A = A;
+    k.M = M;
+    return SCCBF_OK;
+}
+
+// lanes-per-QP when the caller leaves the choice to the library
+int auto_lanes(int64_t A, int M)
+{
+    if (M > 64) return 64;
+    int g;
+    if (A >= (1 << 18)) g = 1;
+    else if (A >= (1 << 17)) g = 2;
+    else if (A >= (1 << 14)) g = 4;
+    else if (A >= 256) g = 16;
+    else return 64;
+    while (g < 16 && M > 16 * g) g *= 2;  // keep at most 16 rows per lane
+    if (M > 16 * g) return 64;
+    return g;
+}
+
+template <typename T, bool QP_ONLY, int G, int RPL>
+int launch_group(const KArgs<T>& k, hipStream_t s)
+{
+    const long long threads = k.A * G;
+    const long long blocks = (threads + kBlock - 1) / kBlock;
+    if (blocks > 0x7fffffffLL) return SCCBF_ERR_ARG;
+    hipLaunchKernelGGL((k_group<T, G, RPL, QP_ONLY>), dim3((unsigned)blocks), dim3(kBlock), 0, s, k);
+    return hipGetLastError() == hipSuccess ? SCCBF_OK : SCCBF_ERR_LAUNCH;
+}
+
+template <typename T, bool QP_ONLY, int G>
+int launch_group_rpl(const KArgs<T>& k, hipStream_t s)
+{
+    const int rpl = (k.M + G - 1) / G;
+    if (rpl <= 1) return launch_group<T, QP_ONLY, G, 1>(k, s);
+    if (rpl <= 2) return launch_group<T, QP_ONLY, G, 2>(k, s);
+    if (rpl <= 4) return launch_group<T, QP_ONLY, G, 4>(k, s);
+    if (rpl <= 8) return launch_group<T, QP_ONLY, G, 8>(k, s);
+    if (rpl <= 16) return launch_group<T, QP_ONLY, G, 16>(k, s);
+    return SCCBF_ERR_VARIANT;
+}
+
+template <typename T, bool QP_ONLY>
+int launch_wave(const KArgs<T>& k, hipStream_t s)
+{
+    const size_t per_wave = (size_t)3 * k.M * sizeof(T);
+    if (per_wave * 4 <= 48 * 1024) {
+        const long long blocks = (k.A + 3) / 4;
+        if (blocks > 0x7fffffffLL) return SCCBF_ERR_ARG;
+        hipLaunchKernelGGL((k_wave<T, 4, QP_ONLY>), dim3((unsigned)blocks), dim3(256), per_wave * 4, s, k);
+    } else {
+        if (k.A > 0x7fffffffLL) return SCCBF_ERR_ARG;
+        hipLaunchKernelGGL((k_wave<T, 1, QP_ONLY>), dim3((unsigned)k.A), dim3(64), per_wave, s, k);
+    }
+    return hipGetLastError() == hipSuccess ? SCCBF_OK : SCCBF_ERR_LAUNCH;
+}
+
+template <typename T, bool QP_ONLY>
+int dispatch(const sccbf_params* sp, KArgs<T>& k, void* stream)
+{
+    if (k.A == 0) return SCCBF_OK;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    int lanes = sp->lanes_per_qp;
+    if (lanes == 0) lanes = auto_lanes(k.A, k.M);
+    if (k.M == 0) lanes = 1;
+    switch (lanes) {
+    case 1: return launch_group_rpl<T, QP_ONLY, 1>(k, s);
+    case 2: return launch_group_rpl<T, QP_ONLY, 2>(k, s);
+    case 4: return launch_group_rpl<T, QP_ONLY, 4>(k, s);
+    case 8: return launch_group_rpl<T, QP_ONLY, 8>(k, s);
+    case 16: return launch_group_rpl<T, QP_ONLY, 16>(k, s);
+    case 64: return launch_wave<T, QP_ONLY>(k, s);
+    default: return SCCBF_ERR_VARIANT;
+    }
+}
+
+template <typename T>
+int solve_impl(const sccbf_params* sp, int64_t A, int32_t M, const T* state, const T* u_ref,
+               const T* obs, const uint8_t* obs_type, T* u_out, int32_t* status, T* rows_out,
+               void* stream)
+{
+    KArgs<T> k;
+    int rc = fill_args<T>(sp, A, M, k);
+    if (rc != SCCBF_OK) return rc;
+    if (A > 0 && (!state || !u_ref || !u_out || !status)) return SCCBF_ERR_ARG;
+    if (A > 0 && M > 0 && (!obs || !obs_type)) return SCCBF_ERR_ARG;
+    k.state = state; k.u_ref = u_ref; k.obs = obs; k.obs_type = obs_type;
+    k.u_out = u_out; k.status = status; k.rows_out = rows_out;
+    return dispatch<T, false>(sp, k, stream);
+}
+
+template <typename T>
+int qp_impl(const sccbf_params* sp, int64_t A, int32_t M, const T* rows, const T* u_nom,
+            T* u_out, int32_t* status, void* stream)
+{
+    KArgs<T> k;
+    sccbf_params q;
+    if (!sp) return SCCBF_ERR_ARG;
+    q = *sp;
+    q.dynamics = SCCBF_DYN_DBM;  // unused by the QP stage; keep validation independent of it
+    if (!(q.lr > 0.0)) q.lr = 1.0;
+    if (!(q.lf + q.lr > 0.0)) q.lf = 1.0;
+    q.flags = 0;
+    int rc = fill_args<T>(&q, A, M, k);
+    if (rc != SCCBF_OK) return rc;
+    if (A > 0 && (!u_nom || !u_out || !status)) return SCCBF_ERR_ARG;
+    if (A > 0 && M > 0 && !rows) return SCCBF_ERR_ARG;
+    k.state = nullptr; k.u_ref = u_nom; k.obs = rows; k.obs_type = nullptr;
+    k.u_out = u_out; k.status = status; k.rows_out = nullptr;
+    return dispatch<T, true>(&q, k, stream);
+}
+
+}  // namespace
+
+extern "C" {
+
+int sccbf_version(void) { return SCCBF_VERSION; }
+
+const char* sccbf_strerror(int code)
+{
+    switch (code) {
+    case SCCBF_OK: return "ok";
+    case SCCBF_ERR_ARG: return "invalid argument (null pointer, negative size or bad enum)";
+    case SCCBF_ERR_ROWS: return "too many constraint rows (M > SCCBF_MAX_ROWS)";
+    case SCCBF_ERR_WEIGHT: return "QP weight R is not symmetric positive definite";
+    case SCCBF_ERR_LAUNCH: return "kernel launch failed";
+    case SCCBF_ERR_VARIANT: return "lanes_per_qp cannot hold M rows (use 0 or 64)";
+    case SCCBF_ERR_NO_DEVICE: return "no usable HIP device";
+    default: return "unknown error";
+    }
+}
+
+void sccbf_default_params(sccbf_params* p)
+{
+    if (!p) return;
+    p->alpha = 1.0;
+    p->lr = 1.45;
+    p->lf = 1.45;
+    p->L = 2.9;
+    p->R[0] = 1.0; p->R[1] = 0.0; p->R[2] = 0.0; p->R[3] = 1.0;
+    p->zero_tol = 1e-3;
+    p->dynamics = SCCBF_DYN_DBM;
+    p->lanes_per_qp = 0;
+    p->flags = 0;
+    p->reserved = 0;
+}
+
+int sccbf_solve_f32(const sccbf_params* p, int64_t A, int32_t M, const float* state,
+                    const float* u_ref, const float* obs, const uint8_t* obs_type, float* u_out,
+                    int32_t* status, float* rows_out, void* stream)
+{
+    return solve_impl<float>(p, A, M, state, u_ref, obs, obs_type, u_out, status, rows_out, stream);
+}
+
+int sccbf_solve_f64(const sccbf_params* p, int64_t A, int32_t M, const double* state,
+                    const double* u_ref, const double* obs, const uint8_t* obs_type, double* u_out,
+                    int32_t* status, double* rows_out, void* stream)
+{
+    return solve_impl<double>(p, A, M, state, u_ref, obs, obs_type, u_out, status, rows_out, stream);
+}
+
+int sccbf_qp_f32(const sccbf_params* p, int64_t A, int32_t M, const float* rows, const float* u_nom,
+                 float* u_out, int32_t* status, void* stream)
+{
+    return qp_impl<float>(p, A, M, rows, u_nom, u_out, status, stream);
+}
+
+int sccbf_qp_f64(const sccbf_params* p, int64_t A, int32_t M, const double* rows,
+                 const double* u_nom, double* u_out, int32_t* status, void* stream)
+{
+    return qp_impl<double>(p, A, M, rows, u_nom, u_out, status, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,61 @@
+"""Diagnostic (not collected by pytest): every kernel variant vs the oracle, with statistics.
+
+    python tests/diag_gpu.py [A]
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import oracle as orc  # noqa: E402
+from sccav_cbf_amd import scenarios  # noqa: E402
+from sccav_cbf_amd.batched import BatchedCBF  # noqa: E402
+from tests import parity  # noqa: E402
+
+
+def run(w, dtype, lanes, R=(0.5, 0, 0, 0.5), alpha=1.0):
+    dev = torch.device("cuda:0")
+    f = BatchedCBF(alpha=alpha, R=np.array(R).reshape(2, 2), lanes_per_qp=lanes, slip_io=True)
+    t = {k: torch.from_numpy(v).to(dev) for k, v in w.items()}
+    for k in ("state", "u_ref", "obs"):
+        t[k] = t[k].to(dtype).contiguous()
+    u, st, rows = f.solve(t["state"], t["u_ref"], t["obs"], t["obs_type"], want_rows=True)
+    torch.cuda.synchronize()
+    return u.double().cpu().numpy(), st.cpu().numpy(), rows.double().cpu().numpy()
+
+
+def main():
+    A = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+    for name, w in (("config4", scenarios.config4(A=A, nominal="uniform")),
+                    ("config3", scenarios.config3(A=A)),
+                    ("lanes", scenarios.lanes_and_cones(A=A))):
+        p = orc.make_params(alpha=1.0, R=(0.5, 0, 0, 0.5), flags=orc.FLAG_SLIP_IO)
+        t0 = time.time()
+        uo, so, ro = orc.solve_batch(p, w["state"], w["u_ref"], w["obs"], w["obs_type"], want_rows=True)
+        print(name, "oracle %.3fs; status counts" % (time.time() - t0), np.bincount(so, minlength=3), flush=True)
+        un = w["u_ref"]
+        R = np.array([[0.5, 0], [0, 0.5]])
+        cost_o, viol_o = parity.qp_metrics(uo, un, ro, R)
+        print("   oracle viol max %.3e" % viol_o[so == 0].max())
+        det = parity.active_det(uo, ro)
+        for dtype in (torch.float64, torch.float32):
+            for lanes in (0, 1, 4, 16, 64):
+                ug, sg, rg = run(w, dtype, lanes)
+                rel_rows = np.abs(rg - ro) / (np.abs(ro) + 1e-3)
+                both = (sg == 0) & (so == 0)
+                du = np.abs(ug - uo).max(axis=1) / np.maximum(1.0, np.hypot(uo[:, 0], uo[:, 1]))
+                cost_g, viol_g = parity.qp_metrics(ug, un, ro, R)
+                dc = np.abs(cost_g - cost_o) / (1 + cost_o)
+                well = both & (det >= 1e-3)
+                print("   %s lanes %2d: status mismatch %d/%d rows maxrel %.2e | du max %.2e (well-cond %.2e, p99.9 %.2e) "
+                      "dcost max %.2e viol max %.2e" % (
+                          str(dtype)[-7:], lanes, (sg != so).sum(), A, rel_rows.max(), du[both].max(),
+                          du[well].max(), np.quantile(du[both], 0.999), dc[both].max(), viol_g[both].max()),
+                      flush=True)
+
+
+if __name__ == "__main__":
+    main()
