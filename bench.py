@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""Benchmark of the batched CBF-QP safety filter on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = one control tick (barrier rows + 2-input QP) for one batch of 65536 agents x
+16 obstacle slots (8 ellipse + 8 collision cone, fp32) per GPU.  Inputs are resident in
+HBM before the timed region; the steps walk a ring of distinct batches larger than the
+256 MiB Infinity Cache so every step streams its inputs from HBM.  Ranks hold independent
+batches (weak scaling, no data-path collective).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from sccav_cbf_amd import scenarios  # noqa: E402
+from sccav_cbf_amd.batched import BatchedCBF  # noqa: E402
+
+AGENTS = 65536
+ROWS = 16
+RING = 10                     # distinct batches: 10 x 35.9 MB > 256 MiB
+HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E peak
+
+
+def algorithmic_bytes(A, M, w=4):
+    # per QP: state 4 + u_ref 2 + 8 M obstacle scalars + u_out 2, plus the int32 status
+    return A * (w * (4 + 2 + 8 * M + 2) + 4)
+
+
+def make_ring(rank, device, n=RING, agents=AGENTS):
+    ring = []
+    for b in range(n):
+        w = scenarios.config4(A=agents, seed=1234 + 4 + 1000 * rank + b)
+        t = dict(state=torch.from_numpy(w["state"]).float().to(device),
+                 u_ref=torch.from_numpy(w["u_ref"]).float().to(device),
+                 obs=torch.from_numpy(w["obs"]).float().to(device),
+                 obs_type=torch.from_numpy(w["obs_type"]).to(device),
+                 u_out=torch.empty((agents, 2), dtype=torch.float32, device=device),
+                 status=torch.empty((agents,), dtype=torch.int32, device=device))
+        ring.append(t)
+    return ring
+
+
+def cpu_baseline(seconds=10.0):
+    """The fp64 oracle (OpenMP) on the host cores, on the first batch of the ring."""
+    from oracle import oracle as orc
+    orc.build()
+    threads = min(16, os.cpu_count() or 1)
+    os.environ.setdefault("OMP_NUM_THREADS", str(threads))
+    threads = int(os.environ["OMP_NUM_THREADS"])
+    w = scenarios.config4(A=AGENTS, seed=1234 + 4)
+    p = orc.make_params(alpha=1.0, R=(0.5, 0, 0, 0.5))
+    orc.solve_batch(p, w["state"], w["u_ref"], w["obs"], w["obs_type"])  # warm
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        orc.solve_batch(p, w["state"], w["u_ref"], w["obs"], w["obs_type"])
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": n * AGENTS / dt, "unit": "solves/s", "cores": threads, "kind": "port",
+            "sample": "%d passes of the fp64 C oracle (OpenMP, %d threads) over one 65536-agent x 16-row "
+                      "batch, %.1f s" % (n, threads, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--lanes", type=int, default=0, help="lanes per QP (0 = library default)")
+    ap.add_argument("--agents", type=int, default=AGENTS)
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+
+    A, M = args.agents, ROWS
+    flt = BatchedCBF(alpha=1.0, lr=1.45, lf=1.45, R=np.diag([0.5, 0.5]), lanes_per_qp=args.lanes)
+    ring = make_ring(rank, device, agents=A)
+
+    def step(i):
+        b = ring[i % RING]
+        flt.solve(b["state"], b["u_ref"], b["obs"], b["obs_type"], u_out=b["u_out"], status=b["status"])
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # one hipGraph = one walk over the ring; eager launches cover the remainder
+    graph = None
+    stream = torch.cuda.Stream(device)
+    with torch.cuda.stream(stream):
+        for i in range(RING):
+            step(i)
+        torch.cuda.synchronize()
+        if not args.no_graph:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=stream):
+                for i in range(RING):
+                    step(i)
+
+        def run(k):
+            done = 0
+            if graph is not None:
+                for _ in range(k // RING):
+                    graph.replay()
+                done = (k // RING) * RING
+            for i in range(done, k):
+                step(i)
+
+        run(args.warmup)
+        barrier()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record(stream)
+        run(args.steps)
+        ev1.record(stream)
+        barrier()
+        t1 = time.perf_counter()
+        wall = t1 - t0
+        dev_ms = ev0.elapsed_time(ev1)
+
+        # per-launch kernel duration: event pairs around single eager launches
+        per = []
+        for i in range(4 * RING):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            step(i)
+            e1.record(stream)
+            torch.cuda.synchronize()
+            per.append(e0.elapsed_time(e1))
+        per_launch_ms = float(np.median(per))
+
+    tw = torch.tensor([wall], dtype=torch.float64, device=device)
+    if dist is not None:
+        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+    wall = float(tw.item())
+
+    status = torch.stack([b["status"] for b in ring]).cpu().numpy()
+    counts = np.bincount(status.reshape(-1), minlength=3)
+
+    if rank == 0:
+        total_solves = A * args.steps * world
+        value = total_solves / wall
+        kern_ms = dev_ms / args.steps           # device time per step over the timed region
+        abytes = algorithmic_bytes(A, M)
+        achieved = abytes / (kern_ms * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "CBF-QP solves/sec (2-input, 16-constraint)",
+            "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "C4: %d agents x 16 obstacle rows (8 ellipse + 8 collision cone) per GPU, "
+                                   "DBM filter, alpha=1, R=diag(.5,.5), ring of %d distinct batches" % (A, RING),
+                       "agents_per_gpu": A, "rows": M, "lanes_per_qp": args.lanes,
+                       "launch": "eager" if graph is None else "hipGraph of %d launches" % RING},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "kernel_ms": kern_ms, "event_pair_ms": per_launch_ms,
+                         "algorithmic_bytes_per_launch": abytes},
+            "status_counts": {"optimal": int(counts[0]), "infeasible": int(counts[1]),
+                              "nonfinite": int(counts[2])},
+        }
+        if world == 1 and not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -147,6 +147,19 @@ int sccbf_qp_f64(const sccbf_params* p, int64_t A, int32_t M,
                  const double* rows, const double* u_nom,
                  double* u_out, int32_t* status, void* stream);
 
+/*
+ * Barrier value and partial derivatives of every obstacle slot, without rows or QP:
+ * out is T[M][2][A][4] = (h, dh/dx, dh/dy, dh/dtheta | dh/dv, dh/dt, 0, 0).
+ * Replaces the stacking primitives ObstacleList2D.f/dx/dy/dtheta/dv/dt (reference
+ * cbf/obstacles.py:879-925) and the per-obstacle f/dx/dy/dtheta/dv/dt they call.
+ */
+int sccbf_partials_f32(const sccbf_params* p, int64_t A, int32_t M,
+                       const float* state, const float* obs, const uint8_t* obs_type,
+                       float* out, void* stream);
+int sccbf_partials_f64(const sccbf_params* p, int64_t A, int32_t M,
+                       const double* state, const double* obs, const uint8_t* obs_type,
+                       double* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -14,7 +14,8 @@ FLAG_OBS_SHARED, FLAG_TYPE_PER_AGENT, FLAG_SLIP_IO = 1, 2, 4
 MAX_ROWS = 1024
 
 EXPORTS = ("sccbf_version", "sccbf_strerror", "sccbf_default_params", "sccbf_solve_f32",
-           "sccbf_solve_f64", "sccbf_qp_f32", "sccbf_qp_f64")
+           "sccbf_solve_f64", "sccbf_qp_f32", "sccbf_qp_f64", "sccbf_partials_f32",
+           "sccbf_partials_f64")
 
 
 class Params(C.Structure):
@@ -52,6 +53,10 @@ def load():
         f.restype = C.c_int
         f.argtypes = [C.POINTER(Params), C.c_int64, C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp]
     for name in ("sccbf_qp_f32", "sccbf_qp_f64"):
+        f = getattr(L, name)
+        f.restype = C.c_int
+        f.argtypes = [C.POINTER(Params), C.c_int64, C.c_int32, vp, vp, vp, vp, vp]
+    for name in ("sccbf_partials_f32", "sccbf_partials_f64"):
         f = getattr(L, name)
         f.restype = C.c_int
         f.argtypes = [C.POINTER(Params), C.c_int64, C.c_int32, vp, vp, vp, vp, vp]

@@ -1,0 +1,124 @@
+"""CBF-QP filter classes with the reference's names and call pattern (cbf/cbf.py).
+
+    cbf = DBM_CBF_2DS(alpha=1.0)
+    cbf.set_model_params(lr=lr, lf=lf)
+    cbf.obstacle_list2d.update({0: CollisionCone2D(a_cone, s, s_obs)})
+    cbf.update_state(s=s)
+    cbf.set_qp_cost_weight(np.diag([0.5, 0.5]))
+    a, delta = cbf.solve_cbf(np.array([a_ref, delta_ref]))
+
+The obstacle rows and the 2-input QP run on the GPU through sccbf_solve_f64; the
+reference hands the same problem to cvxopt.solvers.cp (cbf/cbf.py:213).  Results are
+length-2 float arrays (the reference returns a 2x1 cvxopt matrix, indexed u[0], u[1]).
+"""
+import ctypes as C
+
+import numpy as np
+
+from .. import _lib
+from . import _device
+from ._vec import Point2
+from .obstacles import ObstacleList2D
+
+_STATUS = {0: "optimal", 1: "infeasible", 2: "non-finite input"}
+
+
+class _FilterBase:
+    _dynamics = _lib.DYN_DBM
+
+    def __init__(self, alpha=1.0):
+        self.obstacle_list2d = ObstacleList2D()
+        self._alpha = alpha
+        self._p = Point2()
+        self._v = 0
+        self._theta = 0
+        self._R = np.eye(2)
+        self._lr = 1.45
+        self._lf = 1.45
+        self._L = 2.9
+        self.s = np.zeros(4)
+
+    def set_alpha(self, alpha=1.0):
+        self._alpha = alpha
+
+    def set_qp_cost_weight(self, R):
+        R = np.asarray(R, dtype=np.float64)
+        if R.shape != (2, 2):
+            raise ValueError("Expected a symmetrix matrix of size 2 as input. Please check the "
+                             "value of the matrix R you are using.")
+        self._R = R
+
+    def _params(self, flags=0):
+        p = _lib.Params()
+        _lib.load().sccbf_default_params(C.byref(p))
+        p.alpha = float(self._alpha)
+        p.lr, p.lf, p.L = float(self._lr), float(self._lf), float(self._L)
+        for i in range(4):
+            p.R[i] = float(self._R.reshape(-1)[i])
+        p.dynamics = self._dynamics
+        p.flags = flags
+        return p
+
+    def _solve(self, u_ref):
+        if len(self.obstacle_list2d) < 1:
+            raise ValueError("Cannot solve CBF for an empty obstacle list. Update the obstacle "
+                             "list so that it is non-empty in order to move forward.")
+        u_ref = np.asarray(u_ref, dtype=np.float64).reshape(-1)
+        kinds, slots = self.obstacle_list2d.slots()
+        u, status, rows = _device.solve(self._params(), self.s, u_ref, kinds, slots)
+        info = {"x": u.copy(), "status": _STATUS.get(status, "unknown"), "status_code": status,
+                "rows": rows}
+        return info, u
+
+
+class DBM_CBF_2DS(_FilterBase):
+    """Acceleration-controlled dynamic bicycle model, u = [a, delta] (reference
+    cbf/cbf.py:112-220).  Supports Ellipse2D, CollisionCone2D, PolyLane, RadialEllipse2D."""
+    _dynamics = _lib.DYN_DBM
+
+    def update_state(self, s, s_obs_dict=None, buffer=None, **kwargs):
+        self.s = np.asarray(s, dtype=np.float64).reshape(-1)
+        self.s_obs_dict = s_obs_dict
+        self._p = Point2(self.s[0], self.s[1])
+        self._theta = self.s[2]
+        self._v = self.s[3]
+        self.obstacle_list2d.update_state(s=self.s, s_obs_dict=s_obs_dict, buffer=buffer)
+
+    def set_model_params(self, lr, lf):
+        self._lr = lr
+        self._lf = lf
+
+    def gc(self, *args, **kwargs):
+        """Input matrix g(x) of the model, 4x2 (reference cbf/cbf.py:159-161)."""
+        v, th = self._v, self._theta
+        return np.array([[0.0, -v * np.sin(th)], [0.0, v * np.cos(th)], [0.0, v / self._lr], [1.0, 0.0]])
+
+    def fc(self, *args, **kwargs):
+        """Drift f(x), 4x1 (reference cbf/cbf.py:163-164)."""
+        v, th = self._v, self._theta
+        return np.array([[v * np.cos(th)], [v * np.sin(th)], [0.0], [0.0]])
+
+    def solve_cbf(self, u_ref, return_solver=False):
+        info, u = self._solve(u_ref)
+        if return_solver:
+            return info, u
+        return u
+
+
+class KBM_VC_CBF2D(_FilterBase):
+    """Velocity-controlled kinematic bicycle model, u = [v, delta] (reference
+    cbf/cbf.py:33-110); rows use position and heading only."""
+    _dynamics = _lib.DYN_KBM
+
+    def update_state(self, p, theta):
+        self._p = p
+        self._theta = theta
+        self.s = np.array([p.x, p.y, theta, 0.0])
+        self.obstacle_list2d.update_state(s=self.s)
+
+    def set_model_params(self, L):
+        self._L = L
+
+    def solve_cbf(self, u_ref):
+        info, u = self._solve(u_ref)
+        return info, u

@@ -39,7 +39,7 @@ template <> struct VT<double> {
 };
 
 template <typename T> struct KArgs {
-    T alpha, lr, lf, L;
+    T alpha, lr, lf, L, inv_lr, inv_L;
     T l10, inv_l00, inv_l11;  // Cholesky factor of R
     T zero_tol;
     int dynamics;
@@ -56,13 +56,34 @@ template <typename T> struct KArgs {
 };
 
 // ------------------------------------------------------------------ math shims
-__device__ inline void sincos_(float x, float* s, float* c) { sincosf(x, s, c); }
+// fp32: the hardware sin/cos unit (argument in revolutions) after a two-term reduction
+// by 2 pi; 1-ulp rcp / sqrt / rsq instead of the IEEE division and denormal-safe sqrt
+// sequences.  Library sincosf/tanf would pull a Payne-Hanek reduction with a scratch
+// table into every call site.  fp64 keeps the full-accuracy library forms.
+__device__ inline void sincos_(float x, float* s, float* c)
+{
+    const float k = rintf(x * 0.15915494309189535f);
+    float y = fmaf(-k, 6.2831854820251465f, x);
+    y = fmaf(-k, -1.7484555314695172e-7f, y);
+    const float r = y * 0.15915494309189535f;
+    *s = __builtin_amdgcn_sinf(r);
+    *c = __builtin_amdgcn_cosf(r);
+}
 __device__ inline void sincos_(double x, double* s, double* c) { sincos(x, s, c); }
-__device__ inline float sqrt_(float x) { return sqrtf(x); }
+__device__ inline float sqrt_(float x) { return __builtin_amdgcn_sqrtf(x); }
 __device__ inline double sqrt_(double x) { return sqrt(x); }
-__device__ inline float rsqrt_(float x) { return rsqrtf(x); }
+__device__ inline float rsqrt_(float x) { return __builtin_amdgcn_rsqf(x); }
 __device__ inline double rsqrt_(double x) { return 1.0 / sqrt(x); }
-__device__ inline float tan_(float x) { return tanf(x); }
+__device__ inline float rcp_(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ inline double rcp_(double x) { return 1.0 / x; }
+__device__ inline float div_(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+__device__ inline double div_(double a, double b) { return a / b; }
+__device__ inline float tan_(float x)
+{
+    float s, c;
+    sincos_(x, &s, &c);
+    return s * __builtin_amdgcn_rcpf(c);
+}
 __device__ inline double tan_(double x) { return tan(x); }
 __device__ inline float atan2_(float y, float x) { return atan2f(y, x); }
 __device__ inline double atan2_(double y, double x) { return atan2(y, x); }
@@ -137,7 +158,7 @@ template <typename T>
 __device__ inline void ellipse_(T x, T y, const T o[8], Partials<T>& r)
 {
     T xd = x - o[0], yd = y - o[1];
-    T ia2 = T(1) / (o[2] * o[2]), ib2 = T(1) / (o[3] * o[3]);
+    T ia2 = rcp_(o[2] * o[2]), ib2 = rcp_(o[3] * o[3]);
     T st, ct;
     sincos_(o[4], &st, &ct);
     T p = xd * ct + yd * st;
@@ -156,8 +177,8 @@ template <typename T>
 __device__ inline void radial_(T x, T y, T v, const T o[8], Partials<T>& r)
 {
     T xd = x - o[0], yd = y - o[1];
-    T ia2 = T(1) / (o[2] * o[2]), ib2 = T(1) / (o[3] * o[3]);
-    T iv = T(1) / (T(1) + v);
+    T ia2 = rcp_(o[2] * o[2]), ib2 = rcp_(o[3] * o[3]);
+    T iv = rcp_(T(1) + v);
     r.h = xd * xd * ia2 + yd * yd * ib2 - T(1) - o[6] * v * iv;
     r.hx = T(2) * xd * ia2;
     r.hy = T(2) * yd * ib2;
@@ -183,11 +204,11 @@ __device__ inline void cone_(T x, T y, T th, T v, T cth, T sth, const T o[8], T 
     T vn = sqrt_(dvx * dvx + dvy * dvy);
     T cb = eps;
     if (dist > abs_(a)) cb = sqrt_(d2 - a * a) + eps;
-    T cos_phi = (dist > eps) ? cb / dist : T(0);
+    T cos_phi = (dist > eps) ? div_(cb, dist) : T(0);
     T c = cth, sn = sth;
     if (beta != T(0)) sincos_(th + beta, &sn, &c);
-    T icb = T(1) / (cb + eps);
-    T cbn = cb / (vn + eps);
+    T icb = rcp_(cb + eps);
+    T cbn = div_(cb, vn + eps);
     r.h = (xd * dvx + yd * dvy) + dist * vn * cos_phi;
     r.hx = dvx + vn * xd * icb;
     r.hy = dvy + vn * yd * icb;
@@ -216,7 +237,7 @@ template <typename T> __device__ inline T lane_closest_x_(const T c[8], T px, T 
         T g0 = (x - px) * (x - px) + rr * rr;
         T g1 = T(2) * (x - px) + T(2) * rr * df;
         T g2 = T(2) * (T(1) + df * df + rr * ddf);
-        T step = (g2 > T(1e-12)) ? -g1 / g2 : -g1 / (abs_(g2) + T(1));
+        T step = (g2 > T(1e-12)) ? div_(-g1, g2) : div_(-g1, abs_(g2) + T(1));
         if (step == T(0)) break;
         T xn = x + step;
         T glim = g0 * (T(1) + T(8) * Lim<T>::eps);
@@ -244,7 +265,7 @@ __device__ inline void lane_(T x, T y, const T o[8], T eps, Partials<T>& r)
     poly3_(o, cx, g, dg, ddg);
     T eta = T(1) + dg * ddg + dg * dg - y * ddg;
     if (abs_(eta) < eps) eta = eps;
-    T ie = T(2) / eta;
+    T ie = div_(T(2), eta);
     r.h = (cx - x) * (cx - x) + (g - y) * (g - y) - o[4];
     r.hx = ie * ((x - cx) * (eta - T(1)) - (y - g) * dg);
     r.hy = ie * (-(x - cx) * dg + (y - g) * (eta - dg * dg));
@@ -282,7 +303,7 @@ __device__ inline void slot_row_(int type, const T o[8], const Ego<T>& e, const 
         b = -(p.alpha * d.h);
     } else {
         a0 = d.hv;
-        a1 = e.v * (-e.sth * d.hx + e.cth * d.hy) + (e.v / p.lr) * d.hth;
+        a1 = e.v * (-e.sth * d.hx + e.cth * d.hy) + (e.v * p.inv_lr) * d.hth;
         T lf_h = e.v * (e.cth * d.hx + e.sth * d.hy);
         b = -(lf_h + p.alpha * d.h + d.ht);
     }
@@ -335,7 +356,7 @@ __device__ inline void load_ego_(const KArgs<T>& p, long long qp, bool qp_only, 
     if (p.flags & SCCBF_FLAG_SLIP_IO)
         e.un1 = ur1;
     else if (p.dynamics == SCCBF_DYN_KBM)
-        e.un1 = ur0 * tan_(ur1) / p.L;                       // reference cbf/cbf.py:75
+        e.un1 = ur0 * tan_(ur1) * p.inv_L;                       // reference cbf/cbf.py:75
     else
         e.un1 = atan2_(p.lr * tan_(ur1), p.lf + p.lr);       // reference cbf/cbf.py:175
 }
@@ -469,7 +490,7 @@ __global__ __launch_bounds__(kBlock) void k_group(const KArgs<T> p)
             const bool act = (m < first) && !(at0[r] == T(0) && at1[r] == T(0));
             if (act) {
                 if (abs_(cs) > Lim<T>::par_tol) {
-                    const T t = ee / cs;
+                    const T t = div_(ee, cs);
                     if (cs > T(0)) tlo = max_(tlo, t);
                     else thi = min_(thi, t);
                 } else if (ee > T(1e-6) * (abs_(bt[r]) + abs_(cb)) + Lim<T>::tiny_n2) {
@@ -579,7 +600,7 @@ __global__ __launch_bounds__(WPB * 64) void k_wave(const KArgs<T> p)
             const T cs = r0 * d0 + r1 * d1;
             const T ee = rb - (r0 * p0 + r1 * p1);
             if (abs_(cs) > Lim<T>::par_tol) {
-                const T t = ee / cs;
+                const T t = div_(ee, cs);
                 if (cs > T(0)) tlo = max_(tlo, t);
                 else thi = min_(thi, t);
             } else if (ee > T(1e-6) * (abs_(rb) + abs_(cb)) + Lim<T>::tiny_n2) {
@@ -601,6 +622,40 @@ __global__ __launch_bounds__(WPB * 64) void k_wave(const KArgs<T> p)
     if (lane == 0 && live) store_result_(p, qp, QP_ONLY, st, w0, w1, e, ur0, ur1);
 }
 
+// ------------------------------------- barrier value and partials only (no rows, no QP)
+// One thread per (slot, agent); out is T[M][2][A][4] = (h, h_x, h_y, h_theta | h_v, h_t, 0, 0).
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_partials(const KArgs<T> p)
+{
+    using v4 = typename VT<T>::v4;
+    const long long gid = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (gid >= p.A * p.M) return;
+    const int m = (int)(gid / p.A);
+    const long long a = gid % p.A;
+    const bool shared = (p.flags & SCCBF_FLAG_OBS_SHARED) != 0;
+    const bool type_pa = (p.flags & SCCBF_FLAG_TYPE_PER_AGENT) != 0;
+    const v4* obs4 = reinterpret_cast<const v4*>(p.obs);
+    const long long i0 = shared ? (long long)m * 2 : (long long)m * 2 * p.A + a;
+    const v4 oa = obs4[i0];
+    const v4 ob = obs4[i0 + (shared ? 1 : p.A)];
+    const int ty = type_pa ? p.obs_type[(long long)m * p.A + a] : p.obs_type[m];
+    const v4 s = reinterpret_cast<const v4*>(p.state)[a];
+    T sth, cth;
+    sincos_(s.z, &sth, &cth);
+    const T o[8] = {oa.x, oa.y, oa.z, oa.w, ob.x, ob.y, ob.z, ob.w};
+    Partials<T> d;
+    switch (ty) {
+    case SCCBF_OBS_ELLIPSE: ellipse_(s.x, s.y, o, d); break;
+    case SCCBF_OBS_CONE: cone_(s.x, s.y, s.z, s.w, cth, sth, o, p.zero_tol, d); break;
+    case SCCBF_OBS_LANE: lane_(s.x, s.y, o, p.zero_tol, d); break;
+    case SCCBF_OBS_RADIAL: radial_(s.x, s.y, s.w, o, d); break;
+    default: d.h = T(1); d.hx = d.hy = d.hth = d.hv = d.ht = T(0); break;
+    }
+    v4* out = reinterpret_cast<v4*>(p.rows_out);
+    out[(long long)m * 2 * p.A + a] = v4{d.h, d.hx, d.hy, d.hth};
+    out[(long long)m * 2 * p.A + p.A + a] = v4{d.hv, d.ht, T(0), T(0)};
+}
+
 // ------------------------------------------------------------------- host side
 template <typename T>
 int fill_args(const sccbf_params* sp, int64_t A, int32_t M, KArgs<T>& k)
@@ -617,6 +672,7 @@ int fill_args(const sccbf_params* sp, int64_t A, int32_t M, KArgs<T>& k)
     if (sp->dynamics == SCCBF_DYN_DBM && !(sp->lr > 0.0 && sp->lf + sp->lr > 0.0)) return SCCBF_ERR_ARG;
     if (sp->dynamics == SCCBF_DYN_KBM && !(sp->L > 0.0)) return SCCBF_ERR_ARG;
     k.alpha = (T)sp->alpha; k.lr = (T)sp->lr; k.lf = (T)sp->lf; k.L = (T)sp->L;
+    k.inv_lr = (T)(1.0 / sp->lr); k.inv_L = (T)(1.0 / sp->L);
     k.l10 = (T)l10; k.inv_l00 = (T)(1.0 / l00); k.inv_l11 = (T)(1.0 / l11);
     k.zero_tol = (T)sp->zero_tol;
     k.dynamics = sp->dynamics;
@@ -713,6 +769,24 @@ int solve_impl(const sccbf_params* sp, int64_t A, int32_t M, const T* state, con
 }
 
 template <typename T>
+int partials_impl(const sccbf_params* sp, int64_t A, int32_t M, const T* state, const T* obs,
+                  const uint8_t* obs_type, T* out, void* stream)
+{
+    KArgs<T> k;
+    int rc = fill_args<T>(sp, A, M, k);
+    if (rc != SCCBF_OK) return rc;
+    if (A == 0 || M == 0) return SCCBF_OK;
+    if (!state || !obs || !obs_type || !out) return SCCBF_ERR_ARG;
+    k.state = state; k.u_ref = nullptr; k.obs = obs; k.obs_type = obs_type;
+    k.u_out = nullptr; k.status = nullptr; k.rows_out = out;
+    const long long blocks = (A * M + kBlock - 1) / kBlock;
+    if (blocks > 0x7fffffffLL) return SCCBF_ERR_ARG;
+    hipLaunchKernelGGL((k_partials<T>), dim3((unsigned)blocks), dim3(kBlock), 0,
+                       reinterpret_cast<hipStream_t>(stream), k);
+    return hipGetLastError() == hipSuccess ? SCCBF_OK : SCCBF_ERR_LAUNCH;
+}
+
+template <typename T>
 int qp_impl(const sccbf_params* sp, int64_t A, int32_t M, const T* rows, const T* u_nom,
             T* u_out, int32_t* status, void* stream)
 {
@@ -792,6 +866,18 @@ int sccbf_qp_f64(const sccbf_params* p, int64_t A, int32_t M, const double* rows
                  const double* u_nom, double* u_out, int32_t* status, void* stream)
 {
     return qp_impl<double>(p, A, M, rows, u_nom, u_out, status, stream);
+}
+
+int sccbf_partials_f32(const sccbf_params* p, int64_t A, int32_t M, const float* state,
+                       const float* obs, const uint8_t* obs_type, float* out, void* stream)
+{
+    return partials_impl<float>(p, A, M, state, obs, obs_type, out, stream);
+}
+
+int sccbf_partials_f64(const sccbf_params* p, int64_t A, int32_t M, const double* state,
+                       const double* obs, const uint8_t* obs_type, double* out, void* stream)
+{
+    return partials_impl<double>(p, A, M, state, obs, obs_type, out, stream);
 }
 
 }  // extern "C"

@@ -1,0 +1,86 @@
+"""The C-ABI library: loads, exports every declared symbol, validates arguments on the host
+(no kernel is launched here, so this runs without a GPU)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from sccav_cbf_amd import _build, _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if _build.needs_build():
+        _build.build_library()
+    return _lib.load()
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "sccbf.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(sccbf_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported(lib):
+    names = _declared_symbols()
+    assert set(names) == set(_lib.EXPORTS), (names, _lib.EXPORTS)
+    for n in names:
+        assert hasattr(lib, n), n
+
+
+def test_version_and_strerror(lib):
+    assert lib.sccbf_version() == 100
+    assert lib.sccbf_strerror(0) == b"ok"
+    for code in range(-6, 0):
+        assert len(lib.sccbf_strerror(code)) > 3
+    assert lib.sccbf_strerror(-99) == b"unknown error"
+
+
+def test_params_struct_layout_and_defaults(lib):
+    assert C.sizeof(_lib.Params) == 9 * 8 + 4 * 4
+    p = _lib.Params()
+    lib.sccbf_default_params(C.byref(p))
+    assert (p.alpha, p.lr, p.lf, p.L, p.zero_tol) == (1.0, 1.45, 1.45, 2.9, 1e-3)
+    assert list(p.R) == [1.0, 0.0, 0.0, 1.0]
+    assert (p.dynamics, p.lanes_per_qp, p.flags) == (0, 0, 0)
+
+
+def test_host_side_argument_validation(lib):
+    p = _lib.Params()
+    lib.sccbf_default_params(C.byref(p))
+    nul = C.c_void_p(0)
+    args = (nul,) * 8
+    assert lib.sccbf_solve_f32(None, 1, 1, *args) == -1                 # no params
+    assert lib.sccbf_solve_f32(C.byref(p), -1, 1, *args) == -1          # negative batch
+    assert lib.sccbf_solve_f32(C.byref(p), 1, _lib.MAX_ROWS + 1, *args) == -2
+    assert lib.sccbf_solve_f64(C.byref(p), 4, 2, *args) == -1           # null data pointers
+    assert lib.sccbf_solve_f64(C.byref(p), 0, 2, *args) == 0            # empty batch: nothing to do
+    assert lib.sccbf_qp_f32(C.byref(p), 0, 3, nul, nul, nul, nul, nul) == 0
+    assert lib.sccbf_partials_f64(C.byref(p), 0, 3, nul, nul, nul, nul, nul) == 0
+    p.R[0], p.R[3] = 1.0, -1.0
+    assert lib.sccbf_solve_f32(C.byref(p), 1, 1, *args) == -3           # R not positive definite
+    p.R[3] = 1.0
+    p.R[1] = p.R[2] = 2.0
+    assert lib.sccbf_solve_f32(C.byref(p), 1, 1, *args) == -3
+    p.R[1] = p.R[2] = 0.0
+    p.dynamics = 7
+    assert lib.sccbf_solve_f32(C.byref(p), 1, 1, *args) == -1
+    p.dynamics = 0
+    p.lr = 0.0
+    assert lib.sccbf_solve_f32(C.byref(p), 1, 1, *args) == -1
+
+
+def test_no_cpu_fallback_in_front_end():
+    """Without a GPU the batched front-end must refuse, not compute somewhere else."""
+    import numpy as np
+    import torch
+    from sccav_cbf_amd.batched import BatchedCBF
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    f = BatchedCBF(R=np.eye(2))
+    z = torch.zeros((1, 4))
+    with pytest.raises(_lib.SccbfError):
+        f.solve(z, torch.zeros((1, 2)), torch.zeros((1, 2, 1, 4)), torch.zeros((1,), dtype=torch.uint8))

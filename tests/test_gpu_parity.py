@@ -1,0 +1,301 @@
+"""Parity of the HIP path (through the C ABI) with the fp64 oracle.  Needs an MI355X.
+
+Bars
+  fp64   status identical; |du| <= 1e-8 max(1, |u|)
+  fp32   stated fp64 -> fp32 tolerance: feasibility a.u - b >= -1e-4 (|a||u| + |b|);
+         cost within 2e-3 (1 + cost); |du| <= 1e-3 max(1, |u|) where the active pair is
+         well conditioned (|sin| >= 1e-3); status identical except within 1e-4 of the
+         feasibility boundary (none observed on these seeds)
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from sccav_cbf_amd import _lib, scenarios  # noqa: E402
+from tests import parity  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+R_HALF = np.diag([0.5, 0.5])
+ALL_LANES = (0, 1, 2, 4, 8, 16, 64)
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+def _filter(lanes=0, slip_io=False, alpha=1.0, R=R_HALF, dynamics="dbm", **kw):
+    from sccav_cbf_amd.batched import BatchedCBF
+    return BatchedCBF(alpha=alpha, R=R, lanes_per_qp=lanes, slip_io=slip_io, dynamics=dynamics, **kw)
+
+
+def _to_dev(w, dtype):
+    t = {}
+    for k, v in w.items():
+        x = torch.from_numpy(np.ascontiguousarray(v)).to(_dev())
+        t[k] = x.to(dtype).contiguous() if x.dtype.is_floating_point else x
+    return t
+
+
+def _gpu_solve(w, dtype, lanes, slip_io=True, want_rows=True, **kw):
+    f = _filter(lanes=lanes, slip_io=slip_io, **kw)
+    t = _to_dev(w, dtype)
+    out = f.solve(t["state"], t["u_ref"], t["obs"], t["obs_type"], want_rows=want_rows)
+    torch.cuda.synchronize()
+    return [o.double().cpu().numpy() if o.dtype.is_floating_point else o.cpu().numpy() for o in out]
+
+
+def _orc_solve(oracle, w, slip_io=True, alpha=1.0, R=R_HALF, dynamics=0, extra_flags=0):
+    flags = (oracle.FLAG_SLIP_IO if slip_io else 0) | extra_flags
+    p = oracle.make_params(alpha=alpha, R=np.asarray(R).reshape(-1), flags=flags, dynamics=dynamics)
+    return oracle.solve_batch(p, w["state"], w["u_ref"], w["obs"], w["obs_type"], want_rows=True)
+
+
+def _check(ug, sg, uo, so, ro, un, dtype, R=R_HALF):
+    assert (sg == so).all(), "status mismatch on %d agents" % (sg != so).sum()
+    both = so == 0
+    scale = np.maximum(1.0, np.hypot(uo[:, 0], uo[:, 1]))
+    du = np.abs(ug - uo).max(axis=1) / scale
+    if dtype == torch.float64:
+        assert du[both].max(initial=0) <= 1e-8, du[both].max()
+        assert np.array_equal(ug[~both], uo[~both])       # pass-through is exact
+        return
+    cost_o, _ = parity.qp_metrics(uo, un, ro, R)
+    cost_g, viol_g = parity.qp_metrics(ug, un, ro, R)
+    assert viol_g[both].max(initial=0) <= 1e-4, viol_g[both].max()
+    assert (np.abs(cost_g - cost_o)[both] / (1 + cost_o[both])).max(initial=0) <= 2e-3
+    well = both & (parity.active_det(uo, ro) >= 1e-3)
+    assert du[well].max(initial=0) <= 1e-3, du[well].max()
+
+
+SCENARIOS = {
+    "mixed16": lambda: scenarios.config4(A=4096, nominal="uniform"),
+    "ellipse8": lambda: scenarios.config3(A=4096),
+    "lanes2_cones6": lambda: scenarios.lanes_and_cones(A=4096),
+    "radial32": lambda: scenarios.radial_seekers(M=32, A=257, seed=5),
+}
+
+
+@pytest.mark.parametrize("name", list(SCENARIOS))
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("lanes", ALL_LANES)
+def test_solve_matches_oracle(oracle, name, dtype, lanes):
+    w = SCENARIOS[name]()
+    M = w["obs"].shape[0]
+    if lanes not in (0, 64) and M > 16 * lanes:
+        pytest.skip("this variant holds at most 16 rows per lane")
+    uo, so, ro = _orc_solve(oracle, w)
+    ug, sg, rg = _gpu_solve(w, dtype, lanes)
+    _check(ug, sg, uo, so, ro, w["u_ref"], dtype)
+    tol = 1e-9 if dtype == torch.float64 else 5e-2
+    assert (np.abs(rg - ro) / (np.abs(ro) + 1e-3)).max() <= tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
+def test_steering_transform_path(oracle, dtype):
+    """delta -> beta on the way in, beta -> delta on the way out (cbf/cbf.py:175, 216)."""
+    w = scenarios.config3(A=2048)
+    uo, so, _ = _orc_solve(oracle, w, slip_io=False)
+    ug, sg = _gpu_solve(w, dtype, 0, slip_io=False, want_rows=False)
+    assert (sg == so).all()
+    ok = (so == 0) & (np.abs(uo[:, 1]) < 1.2)      # tan is ill-conditioned near pi/2
+    tol = 1e-8 if dtype == torch.float64 else 2e-3
+    assert np.abs(ug - uo)[ok].max() <= tol
+    assert np.allclose(ug[so != 0], w["u_ref"][so != 0], rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
+def test_kbm_dynamics(oracle, dtype):
+    """KBM_VC_CBF2D rows and steering maps (cbf/cbf.py:75, 94-101, 109)."""
+    w = scenarios.config3(A=2048)
+    w["u_ref"][:, 0] = np.abs(w["u_ref"][:, 0]) + 2.0        # v_ref > 0
+    w["u_ref"][:, 1] *= 0.5
+    for slip_io in (True, False):
+        uo, so, ro = _orc_solve(oracle, w, slip_io=slip_io, dynamics=1, R=np.eye(2))
+        ug, sg, rg = _gpu_solve(w, dtype, 0, slip_io=slip_io, dynamics="kbm", R=np.eye(2))
+        assert (sg == so).all()
+        ok = so == 0
+        tol = 1e-8 if dtype == torch.float64 else 2e-3
+        assert (np.abs(ug - uo)[ok].max(axis=1) / np.maximum(1, np.abs(uo[ok]).max(axis=1))).max() <= tol
+
+
+def test_partials_match_oracle(oracle):
+    w = scenarios.lanes_and_cones(A=64, n_cone=3)
+    we = scenarios.monte_carlo(64, 3, 0, 9, nominal="uniform")
+    wr = scenarios.radial_seekers(M=2, A=64, seed=3)
+    wr["state"] = we["state"] * 0.1
+    lib = _lib.load()
+    for ww in (w, we, wr):
+        for dtype, tol in ((torch.float64, 1e-9), (torch.float32, 2e-3)):
+            t = _to_dev(ww, dtype)
+            M, A = ww["obs"].shape[0], ww["state"].shape[0]
+            out = torch.empty((M, 2, A, 4), dtype=dtype, device=_dev())
+            p = _lib.Params()
+            lib.sccbf_default_params(C.byref(p))
+            fn = lib.sccbf_partials_f64 if dtype == torch.float64 else lib.sccbf_partials_f32
+            _lib.check(fn(C.byref(p), A, M, C.c_void_p(t["state"].data_ptr()), C.c_void_p(t["obs"].data_ptr()),
+                          C.c_void_p(t["obs_type"].data_ptr()), C.c_void_p(out.data_ptr()), None))
+            torch.cuda.synchronize()
+            o = out.double().cpu().numpy()
+            for m in range(M):
+                for a in range(0, A, 7):
+                    slot = ww["obs"][m, :, a, :].reshape(8)
+                    d = oracle.barrier(int(ww["obs_type"][m]), ww["state"][a], slot)
+                    got = np.concatenate([o[m, 0, a, :], o[m, 1, a, :2]])
+                    exp = np.array([d["h"], d["hx"], d["hy"], d["hth"], d["hv"], d["ht"]])
+                    assert np.abs(got - exp).max() <= tol * (1 + np.abs(exp).max()), (m, a, got, exp)
+
+
+def _adversarial_rows():
+    cases = [
+        [(1, 0, 1.0), (1, 0, 1.0), (2, 0, 2.0), (1, 1e-13, 1.0), (0, 1, -3)],     # duplicates / parallel
+        [(1, 0, 1.0), (-1, 0, 0.5)],                                               # infeasible pair
+        [(1, 0, 1.0), (-1, 0, -1.0)],                                              # equality x = 1
+        [(0, 0, 1.0)],                                                             # 0.u >= 1
+        [(0, 0, -1.0), (1, 1, 1.0)],                                               # empty row
+        [(1, 0, 1.0), (0, 1, 2.0), (-1, -1, -3.5)],                                # triangle, vertex active
+        [(1, 0, 1.0), (0, 1, 2.0), (-1, -1, -2.9)],                                # empty triangle
+        [(1, 1e-3, 1.0), (1, -1e-3, 1.0)],                                         # nearly parallel
+        [(1e-6, 0, 1e-6), (0, 1e6, -1e6)],                                         # badly scaled
+        [(np.cos(t), np.sin(t), 1.0) for t in np.linspace(0, np.pi / 2, 16)],     # 16 tangents to a circle
+    ]
+    M = max(len(c) for c in cases)
+    rows = np.zeros((M, len(cases), 4))
+    rows[:, :, 2] = -1.0
+    for a, c in enumerate(cases):
+        for m, (a0, a1, b) in enumerate(c):
+            rows[m, a, :3] = (a0, a1, b)
+    return rows
+
+
+@pytest.mark.parametrize("lanes", ALL_LANES)
+def test_qp_stage_adversarial_rows(oracle, lanes):
+    rows = _adversarial_rows()
+    A = rows.shape[1]
+    un = np.zeros((A, 2))
+    un[5] = [0.2, 0.1]
+    p = oracle.make_params(R=(1, 0, 0, 1))
+    uo, so = oracle.qp_batch(p, rows, un)
+    f = _filter(lanes=lanes, R=np.eye(2))
+    r = torch.from_numpy(rows).to(_dev())
+    ug, sg = f.solve_qp(r, torch.from_numpy(un).to(_dev()))
+    torch.cuda.synchronize()
+    ug, sg = ug.cpu().numpy(), sg.cpu().numpy()
+    assert (sg == so).all(), (sg, so)
+    assert np.abs(ug - uo).max() <= 1e-6 * (1 + np.abs(uo).max())
+
+
+@pytest.mark.parametrize("lanes", ALL_LANES)
+@pytest.mark.parametrize("M", [0, 1, 2, 3, 5, 8, 9, 16, 17, 31, 32, 33, 64])
+def test_row_counts_and_ragged_batches(oracle, lanes, M):
+    """Every row count around the register-tile boundaries; batch sizes that do not fill
+    a wavefront or a workgroup; per-agent kinds with empty slots."""
+    if lanes not in (0, 64) and M > 16 * lanes:
+        pytest.skip("this variant holds at most 16 rows per lane")
+    for A in (1, 3, 63, 65, 257):
+        rng = np.random.default_rng(1000 + 7 * M + A)
+        w = scenarios.monte_carlo(A, (M + 1) // 2, M // 2, int(rng.integers(1 << 30)), nominal="uniform") \
+            if M > 0 else dict(state=rng.normal(0, 1, (A, 4)), u_ref=rng.normal(0, 1, (A, 2)),
+                               obs=np.zeros((0, 2, A, 4)), obs_type=np.zeros(0, dtype=np.uint8))
+        kinds = np.repeat(w["obs_type"][:, None], A, axis=1)
+        if M > 0:
+            kinds[rng.uniform(size=kinds.shape) < 0.3] = 255       # ragged: empty slots per agent
+        w["obs_type"] = np.ascontiguousarray(kinds)
+        uo, so, ro = _orc_solve(oracle, w, extra_flags=oracle.FLAG_TYPE_PER_AGENT)
+        ug, sg, rg = _gpu_solve(w, torch.float64, lanes)
+        assert (sg == so).all()
+        assert np.abs(ug - uo).max() <= 1e-8 * (1 + np.abs(uo).max())
+        if M == 0:
+            assert np.array_equal(ug, w["u_ref"])
+
+
+def test_shared_obstacle_table(oracle):
+    w = scenarios.config4(A=1000, nominal="uniform")
+    w["obs"] = np.ascontiguousarray(w["obs"][:, :, 17, :])        # (M,2,4): one table for all
+    w["state"][:, :2] = w["state"][17, :2] + np.random.default_rng(0).normal(0, 3, (1000, 2))
+    p = oracle.make_params(R=(0.5, 0, 0, 0.5), flags=oracle.FLAG_OBS_SHARED | oracle.FLAG_SLIP_IO)
+    uo, so, _ = oracle.solve_batch(p, w["state"], w["u_ref"], w["obs"], w["obs_type"])
+    for lanes in (0, 1, 4, 64):
+        ug, sg = _gpu_solve(w, torch.float64, lanes, want_rows=False)
+        assert (sg == so).all() and np.abs(ug - uo).max() <= 1e-8 * (1 + np.abs(uo).max())
+
+
+def test_nonfinite_inputs_are_flagged(oracle):
+    w = scenarios.config4(A=300, nominal="uniform")
+    w["state"][5, 0] = np.nan
+    w["u_ref"][9, 1] = np.inf
+    w["obs"][3, 0, 20, 2] = np.nan
+    w["obs"][12, 1, 31, 0] = -np.inf
+    uo, so, _ = _orc_solve(oracle, w)
+    assert list(np.where(so == 2)[0]) == [5, 9, 20, 31]
+    for dtype in (torch.float64, torch.float32):
+        for lanes in (1, 4, 64):
+            ug, sg = _gpu_solve(w, dtype, lanes, want_rows=False)
+            assert (sg == so).all()
+            assert np.allclose(ug[so == 2], w["u_ref"][so == 2], equal_nan=True)
+
+
+def test_maximum_row_count(oracle):
+    """M = SCCBF_MAX_ROWS through the one-wavefront-per-QP kernel (rows in LDS)."""
+    M, A = _lib.MAX_ROWS, 9
+    w = scenarios.monte_carlo(A, M // 2, M // 2, 77, nominal="uniform")
+    w["obs"][:, 0, :, 0] += 400.0            # push obstacles away so the set stays feasible
+    uo, so, _ = _orc_solve(oracle, w)
+    ug, sg = _gpu_solve(w, torch.float64, 0, want_rows=False)
+    assert (sg == so).all() and np.abs(ug - uo).max() <= 1e-8 * (1 + np.abs(uo).max())
+    f = _filter()
+    t = _to_dev(scenarios.monte_carlo(2, M // 2 + 1, M // 2, 1, nominal="uniform"), torch.float64)
+    with pytest.raises(_lib.SccbfError):
+        f.solve(t["state"], t["u_ref"], t["obs"], t["obs_type"])
+
+
+def test_full_size_batch_properties(oracle):
+    """C4 at full size (65536 x 16, fp32): shard invariance, feasibility of every answer
+    against the kernel's own rows, idempotence of the projection, and the oracle on a
+    4096-agent sample."""
+    w = scenarios.config4(A=65536, nominal="uniform")
+    t = _to_dev(w, torch.float32)
+    f = _filter(slip_io=True)
+    u, st, rows = f.solve(t["state"], t["u_ref"], t["obs"], t["obs_type"], want_rows=True)
+    # (i) two shards give the bits of the full batch
+    h = 65536 // 2
+    for lo in (0, h):
+        us, ss = f.solve(t["state"][lo:lo + h].contiguous(), t["u_ref"][lo:lo + h].contiguous(),
+                         t["obs"][:, :, lo:lo + h, :].contiguous(), t["obs_type"])
+        assert torch.equal(us, u[lo:lo + h]) and torch.equal(ss, st[lo:lo + h])
+    # (ii) feasibility in fp64 on the device
+    r64, u64 = rows.double(), u.double()
+    lhs = r64[:, :, 0] * u64[None, :, 0] + r64[:, :, 1] * u64[None, :, 1]
+    scale = torch.hypot(r64[:, :, 0], r64[:, :, 1]) * torch.hypot(u64[:, 0], u64[:, 1])[None, :] + r64[:, :, 2].abs()
+    viol = ((r64[:, :, 2] - lhs) / (scale + 1e-30)).max(dim=0).values
+    ok = st == 0
+    assert ok.sum().item() > 30000
+    assert viol[ok].max().item() <= 1e-4
+    # (iii) a feasible answer is its own projection
+    u2, st2 = f.solve(t["state"], u.contiguous(), t["obs"], t["obs_type"])
+    assert (st2[ok] == 0).all()
+    assert ((u2 - u)[ok].abs().max(dim=1).values / (1 + u[ok].abs().max(dim=1).values)).max().item() <= 2e-4
+    # (iv) oracle on a sample
+    idx = np.random.default_rng(3).choice(65536, 4096, replace=False)
+    ws = dict(state=w["state"][idx], u_ref=w["u_ref"][idx], obs=np.ascontiguousarray(w["obs"][:, :, idx, :]),
+              obs_type=w["obs_type"])
+    uo, so, ro = _orc_solve(oracle, ws)
+    _check(u.double().cpu().numpy()[idx], st.cpu().numpy()[idx], uo, so, ro, ws["u_ref"], torch.float32)
+
+
+@pytest.mark.parametrize("alpha", [0.5, 1.0, 5.0])
+def test_fp32_vs_fp64_tolerance_sweep(oracle, alpha):
+    """C5: lanes + cones, 16384 agents: fp32 against fp64 on the GPU, and fp64 against the oracle."""
+    w = scenarios.lanes_and_cones(A=16384)
+    u64, s64, r64 = _gpu_solve(w, torch.float64, 0, alpha=alpha)
+    u32, s32, r32 = _gpu_solve(w, torch.float32, 0, alpha=alpha)
+    uo, so, ro = _orc_solve(oracle, w, alpha=alpha)
+    _check(u64, s64, uo, so, ro, w["u_ref"], torch.float64)
+    _check(u32, s32, u64, s64, r64, w["u_ref"], torch.float32)
+    both = (s64 == 0) & (s32 == 0)
+    du = np.abs(u32 - u64).max(axis=1)[both]
+    print("alpha %.1f: max|du| %.3e  p99.9 %.3e  status agreement %.5f" % (
+        alpha, du.max(), np.quantile(du, 0.999), (s32 == s64).mean()))

@@ -1,0 +1,134 @@
+"""The oracle's exact QP against closed forms, a second algorithm, SciPy and KKT (CPU only)."""
+import numpy as np
+import pytest
+from scipy.optimize import minimize
+
+
+def _params(orc, R=(1.0, 0, 0, 1.0)):
+    return orc.make_params(R=R)
+
+
+def _rows(arr):
+    """list of (a0, a1, b) for one agent -> (M, 1, 4)"""
+    r = np.zeros((len(arr), 1, 4))
+    for i, (a0, a1, b) in enumerate(arr):
+        r[i, 0, :3] = (a0, a1, b)
+    return r
+
+
+def test_no_active_row_returns_nominal(oracle):
+    u, st = oracle.qp_batch(_params(oracle), _rows([(1, 0, -5), (0, 1, -2), (-1, -1, -9)]), np.array([[0.3, -0.2]]))
+    assert st[0] == 0 and np.allclose(u[0], [0.3, -0.2], atol=1e-15)
+
+
+@pytest.mark.parametrize("R", [np.eye(2), np.diag([0.5, 0.5]), np.array([[2.0, 0.3], [0.3, 0.7]])])
+def test_single_active_row_closed_form(oracle, R):
+    """u = u_nom + R^-1 a (b - a.u_nom) / (a R^-1 a^T)"""
+    a, b, un = np.array([1.5, -0.7]), 2.0, np.array([0.2, 0.4])
+    u, st = oracle.qp_batch(_params(oracle, R.reshape(-1)), _rows([(a[0], a[1], b), (0, 1, -50)]), un[None, :])
+    Ri = np.linalg.inv(R)
+    expect = un + Ri @ a * (b - a @ un) / (a @ Ri @ a)
+    assert st[0] == 0 and np.allclose(u[0], expect, atol=1e-12)
+
+
+def test_two_active_rows_vertex(oracle):
+    rows = [(1, 0, 1.0), (0, 1, 2.0)]
+    u, st = oracle.qp_batch(_params(oracle), _rows(rows), np.zeros((1, 2)))
+    assert st[0] == 0 and np.allclose(u[0], [1.0, 2.0], atol=1e-12)
+
+
+def test_infeasible_and_zero_rows(oracle):
+    p = _params(oracle)
+    u, st = oracle.qp_batch(p, _rows([(1, 0, 1.0), (-1, 0, 0.5)]), np.array([[0.1, 0.2]]))
+    assert st[0] == 1 and np.allclose(u[0], [0.1, 0.2])          # pass-through
+    u, st = oracle.qp_batch(p, _rows([(0, 0, 1.0)]), np.zeros((1, 2)))
+    assert st[0] == 1                                             # 0.u >= 1
+    u, st = oracle.qp_batch(p, _rows([(0, 0, -1.0), (1, 1, 1.0)]), np.zeros((1, 2)))
+    assert st[0] == 0 and np.allclose(u[0], [0.5, 0.5])           # empty row ignored
+    u, st = oracle.qp_batch(p, _rows([(np.nan, 0, 1.0)]), np.zeros((1, 2)))
+    assert st[0] == 2
+
+
+def _random_rows(rng, A, M, un=None):
+    """Random half-planes; 85 % of the agents get rows that all contain a common point near
+    u_nom (feasible by construction), the rest arbitrary offsets (often infeasible)."""
+    ang = rng.uniform(0, 2 * np.pi, (M, A))
+    scale = np.exp(rng.uniform(-2, 2, (M, A)))
+    rows = np.zeros((M, A, 4))
+    rows[..., 0] = np.cos(ang) * scale
+    rows[..., 1] = np.sin(ang) * scale
+    z = rng.normal(0, 1.5, (A, 2)) + (0 if un is None else un)
+    az = rows[..., 0] * z[None, :, 0] + rows[..., 1] * z[None, :, 1]
+    slack = np.abs(rng.normal(0, 1.0, (M, A)))
+    wild = rng.uniform(size=A) < 0.15
+    slack[:, wild] = rng.normal(0.3, 1.0, (M, int(wild.sum())))
+    rows[..., 2] = az - slack * scale
+    return rows
+
+
+@pytest.mark.parametrize("M", [1, 2, 3, 8, 16, 32])
+def test_enumeration_agrees_with_incremental(oracle, M):
+    rng = np.random.default_rng(100 + M)
+    A = 2000
+    un = rng.normal(0, 1, (A, 2))
+    rows = _random_rows(rng, A, M, un)
+    p = _params(oracle, (0.8, 0.1, 0.1, 0.5))
+    u1, s1 = oracle.qp_batch(p, rows, un)
+    u2, s2 = oracle.qp_batch(p, rows, un, incremental=True)
+    assert (s1 == s2).all()
+    ok = s1 == 0
+    assert ok.sum() > A // 2
+    assert np.abs(u1[ok] - u2[ok]).max() < 1e-8
+
+
+def test_degenerate_parallel_and_duplicate_rows(oracle):
+    p = _params(oracle)
+    rows = _rows([(1, 0, 1.0), (1, 0, 1.0), (2, 0, 2.0), (1, 1e-13, 1.0), (0, 1, -3)])
+    for inc in (False, True):
+        u, st = oracle.qp_batch(p, rows, np.zeros((1, 2)), incremental=inc)
+        assert st[0] == 0 and np.allclose(u[0], [1.0, 0.0], atol=1e-9)
+
+
+def test_kkt_residuals(oracle):
+    """Stationarity, primal feasibility, complementary slackness with multipliers >= 0."""
+    rng = np.random.default_rng(7)
+    A, M = 500, 6
+    un = rng.normal(0, 1, (A, 2))
+    rows = _random_rows(rng, A, M, un)
+    R = np.array([[1.3, -0.2], [-0.2, 0.6]])
+    u, st = oracle.qp_batch(_params(oracle, R.reshape(-1)), rows, un)
+    checked = 0
+    for a in np.where(st == 0)[0]:
+        Aa, b = rows[:, a, :2], rows[:, a, 2]
+        slack = Aa @ u[a] - b
+        assert slack.min() > -1e-9 * (1 + np.abs(b).max())
+        act = np.where(slack < 1e-7 * (1 + np.abs(b)))[0]
+        grad = 2 * R @ (u[a] - un[a])
+        if len(act) == 0:
+            assert np.abs(grad).max() < 1e-9
+        else:
+            lam, res, *_ = np.linalg.lstsq(Aa[act].T, grad, rcond=None)
+            assert np.abs(Aa[act].T @ lam - grad).max() < 1e-6 * (1 + np.abs(grad).max())
+            if len(act) <= 2:
+                assert lam.min() > -1e-7 * (1 + np.abs(lam).max())
+        checked += 1
+    assert checked > 50
+
+
+def test_against_scipy_slsqp(oracle):
+    rng = np.random.default_rng(11)
+    A, M = 60, 5
+    un = rng.normal(0, 1, (A, 2))
+    rows = _random_rows(rng, A, M, un)
+    R = np.diag([0.5, 0.5])
+    u, st = oracle.qp_batch(_params(oracle, R.reshape(-1)), rows, un)
+    n = 0
+    for a in np.where(st == 0)[0]:
+        Aa, b = rows[:, a, :2], rows[:, a, 2]
+        res = minimize(lambda x: (x - un[a]) @ R @ (x - un[a]), un[a], jac=lambda x: 2 * R @ (x - un[a]),
+                       constraints=[{"type": "ineq", "fun": lambda x: Aa @ x - b, "jac": lambda x: Aa}],
+                       method="SLSQP", options={"ftol": 1e-14, "maxiter": 200})
+        if res.success:
+            assert np.abs(res.x - u[a]).max() < 1e-5 * (1 + np.abs(u[a]).max()), (a, res.x, u[a])
+            n += 1
+    assert n > 20
