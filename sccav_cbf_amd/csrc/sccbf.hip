@@ -5,17 +5,20 @@
 //
 // Two kernel families share the row and QP arithmetic:
 //   k_group<T, G, RPL>  G cooperating lanes per QP (G = 1, 2, 4, 8, 16), each lane
-//                       keeps RPL rows in registers; cross-lane steps are shuffles
+//                       keeps RPL rows in registers; cross-lane steps are DPP moves
 //                       inside the G-lane group.  G = 1 is one thread per QP.
 //   k_wave<T, WPB>      one 64-lane wavefront per QP, rows staged in LDS, any M;
-//                       first-violated search by ballot, bounds by wave shuffles.
+//                       the most violated row is found by a wave-wide max.
 //
 // The QP (reference cbf/cbf.py:182-213 hands it to cvxopt.solvers.cp) is solved
 // exactly: in w = Lc^T (u - u_nom), R = Lc Lc^T, it is the least-norm point of the
-// polygon { at_i . w >= bt_i }.  Starting from w = 0 the lowest-index violated row
-// is found; the optimum then lies on that row's line, and the 1-D problem along the
-// line bounded by the earlier rows is solved.  Rows are visited in increasing index,
-// so at most M line solves happen per QP.
+// polygon { at_i . w >= bt_i }.  An active-set iteration starts at w = 0 with no
+// active row; while some row is violated, the most violated one is taken: the optimum
+// of {active rows} + {that row} lies on its line, so the 1-D problem along the line,
+// bounded by the (at most two) active rows, is solved, and the rows tight at the new
+// point become the active set.  |w| grows strictly with every step, so no active set
+// repeats; the loop ends with no violated row (optimal) or an empty 1-D interval
+// (three rows without a common point: infeasible).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <cmath>
@@ -102,6 +105,7 @@ template <> struct Lim<float> {
     static constexpr float tiny_n2 = 1e-30f;   // squared row norm below this = zero row
     static constexpr float viol_tol = 2e-6f;   // relative slack of the "violated" test
     static constexpr float par_tol = 1e-6f;    // |sin| below this = parallel rows
+    static constexpr float feas_tol = 1e-6f;   // relative slack of the "bounds cross" test
     static constexpr float lane_xtol = 3e-4f;
 };
 template <> struct Lim<double> {
@@ -109,43 +113,102 @@ template <> struct Lim<double> {
     static constexpr double tiny_n2 = 1e-300;
     static constexpr double viol_tol = 1e-12;
     static constexpr double par_tol = 1e-14;
+    static constexpr double feas_tol = 1e-10;
     static constexpr double lane_xtol = 1e-8;
 };
 
 // ------------------------------------------------------------- cross-lane helpers
 // Reductions over the G consecutive lanes of a cooperative group (G power of two <= 64).
-__device__ inline float shfl_xor_(float v, int m, int w) { return __shfl_xor(v, m, w); }
-__device__ inline int shfl_xor_(int v, int m, int w) { return __shfl_xor(v, m, w); }
-__device__ inline double shfl_xor_(double v, int m, int w) { return __shfl_xor(v, m, w); }
-__device__ inline float shfl_(float v, int l, int w) { return __shfl(v, l, w); }
-__device__ inline double shfl_(double v, int l, int w) { return __shfl(v, l, w); }
+// Inside a 16-lane row the partner exchanges are DPP moves (no LDS round trip):
+// quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror; after each step
+// every lane of the growing sub-group holds that sub-group's result.  Across rows
+// (G = 64 only) the partners come through ds_bpermute.
+template <int CTRL> __device__ inline unsigned dpp_(unsigned v)
+{
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
+}
+struct OpMax { __device__ unsigned operator()(unsigned a, unsigned b) const { return a > b ? a : b; } };
+struct OpOr { __device__ unsigned operator()(unsigned a, unsigned b) const { return a | b; } };
 
-template <int G, typename T> __device__ inline T group_max(T v)
+template <int G, typename Op> __device__ inline unsigned group_reduce(unsigned v, Op op)
 {
-#pragma unroll
-    for (int o = G / 2; o > 0; o >>= 1) v = max_(v, shfl_xor_(v, o, G));
+    if (G >= 2) v = op(v, dpp_<0xB1>(v));
+    if (G >= 4) v = op(v, dpp_<0x4E>(v));
+    if (G >= 8) v = op(v, dpp_<0x141>(v));
+    if (G >= 16) v = op(v, dpp_<0x140>(v));
+    if (G >= 32) v = op(v, (unsigned)__shfl_xor((int)v, 16, 64));
+    if (G >= 64) v = op(v, (unsigned)__shfl_xor((int)v, 32, 64));
     return v;
 }
-template <int G, typename T> __device__ inline T group_min(T v)
+template <int G> __device__ inline unsigned group_umax(unsigned v) { return group_reduce<G>(v, OpMax()); }
+template <int G> __device__ inline unsigned group_or(unsigned v) { return group_reduce<G>(v, OpOr()); }
+// value held by exactly one lane of the group (the others pass `mine = false`) -> all lanes
+template <int G> __device__ inline float group_pick(float v, bool mine)
 {
-#pragma unroll
-    for (int o = G / 2; o > 0; o >>= 1) v = min_(v, shfl_xor_(v, o, G));
-    return v;
+    return __uint_as_float(group_or<G>(mine ? __float_as_uint(v) : 0u));
 }
-template <int G> __device__ inline int group_imin(int v)
+template <int G> __device__ inline double group_pick(double v, bool mine)
 {
-#pragma unroll
-    for (int o = G / 2; o > 0; o >>= 1) {
-        int t = shfl_xor_(v, o, G);
-        v = t < v ? t : v;
+    const unsigned long long b = mine ? (unsigned long long)__double_as_longlong(v) : 0ull;
+    const unsigned lo = group_or<G>((unsigned)b), hi = group_or<G>((unsigned)(b >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+// order-preserving 32-bit image of a positive violation (fp64 is narrowed first)
+__device__ inline unsigned viol_bits(float v) { return __float_as_uint(v); }
+__device__ inline unsigned viol_bits(double v) { return __float_as_uint(fmaxf((float)v, 1.17549435e-38f)); }
+
+// ------------------------------------------------------------------- the 2-D QP
+// State of the active-set iteration, identical in every lane of a cooperative group:
+// the current optimum w and the (at most two) rows that are active at it.
+template <typename T> struct Pivot {
+    T w0, w1;
+    T sa0[2], sa1[2], sb[2];
+    int ns;
+    int st;
+};
+
+// Move the optimum onto the violated row c . w = cb (unit normal c): the new optimum of
+// {active rows} + {this row} lies on that line; along it, w = p + t d, the active rows
+// bound t and the point nearest to the origin inside the bounds is taken.  The row that
+// clamps t (if any) stays active, the other one is released.
+template <typename T> __device__ inline void pivot_onto_(Pivot<T>& s, T c0, T c1, T cb)
+{
+    if (c0 == T(0) && c1 == T(0)) {  // 0 . u >= positive
+        s.st = SCCBF_STATUS_INFEASIBLE;
+        return;
     }
-    return v;
-}
-template <int G> __device__ inline int group_or(int v)
-{
+    const T p0 = c0 * cb, p1 = c1 * cb;
+    const T d0 = -c1, d1 = c0;
+    T tlo = -INFINITY, thi = INFINITY;
+    int jlo = -1, jhi = -1;
+    bool inf = false;
 #pragma unroll
-    for (int o = G / 2; o > 0; o >>= 1) v |= shfl_xor_(v, o, G);
-    return v;
+    for (int j = 0; j < 2; ++j) {
+        if (j < s.ns) {
+            const T cs = s.sa0[j] * d0 + s.sa1[j] * d1;
+            const T ee = s.sb[j] - (s.sa0[j] * p0 + s.sa1[j] * p1);
+            if (abs_(cs) > Lim<T>::par_tol) {
+                const T t = div_(ee, cs);
+                if (cs > T(0)) { if (t > tlo) { tlo = t; jlo = j; } }
+                else { if (t < thi) { thi = t; jhi = j; } }
+            } else if (ee > Lim<T>::feas_tol * (abs_(s.sb[j]) + abs_(cb)) + Lim<T>::tiny_n2) {
+                inf = true;  // parallel rows facing each other with a gap
+            }
+        }
+    }
+    if (inf || tlo > thi + Lim<T>::feas_tol * (abs_(tlo) + abs_(thi))) {
+        s.st = SCCBF_STATUS_INFEASIBLE;
+        return;
+    }
+    T t = T(0);
+    int keep = -1;
+    if (tlo > T(0)) { t = tlo; keep = jlo; }
+    else if (thi < T(0)) { t = thi; keep = jhi; }
+    s.w0 = p0 + t * d0;
+    s.w1 = p1 + t * d1;
+    if (keep == 0) { s.sa0[1] = s.sa0[0]; s.sa1[1] = s.sa1[0]; s.sb[1] = s.sb[0]; }  // keep == 1 stays put
+    s.sa0[0] = c0; s.sa1[0] = c1; s.sb[0] = cb;
+    s.ns = keep >= 0 ? 2 : 1;
 }
 
 // --------------------------------------------------------------------- barriers
@@ -217,7 +280,7 @@ __device__ inline void cone_(T x, T y, T th, T v, T cth, T sth, const T o[8], T 
     r.ht = (-dvx * ovx - dvy * ovy) - vn * (xd * ovx + yd * ovy) * icb;
 }
 
-template <typename T> __device__ inline void poly3_(const T c[8], T x, T& f, T& df, T& ddf)
+template <typename T> __device__ inline void poly3_(const T c[4], T x, T& f, T& df, T& ddf)
 {
     f = c[0] + x * (c[1] + x * (c[2] + x * c[3]));
     df = c[1] + x * (T(2) * c[2] + x * T(3) * c[3]);
@@ -227,9 +290,14 @@ template <typename T> __device__ inline void poly3_(const T c[8], T x, T& f, T& 
 // Abscissa of the curve point nearest to (px, py): descent from x0 = px, Newton with
 // the true curvature, halving until the distance does not grow.  Replaces the scipy
 // Newton-CG call of PolyLane.get_shortest_distance_x, reference cbf/obstacles.py:641-679.
-template <typename T> __device__ inline T lane_closest_x_(const T c[8], T px, T py)
+// Kept out of line (one copy, rolled loops): lanes are a minority of the rows and the
+// iteration would otherwise be replicated into every unrolled row of the kernels.
+template <typename T>
+__device__ __noinline__ T lane_closest_x_(T c0, T c1, T c2, T c3, T px, T py)
 {
+    const T c[4] = {c0, c1, c2, c3};
     T x = px;
+#pragma nounroll
     for (int it = 0; it < kLaneIters; ++it) {
         T f, df, ddf;
         poly3_(c, x, f, df, ddf);
@@ -241,6 +309,7 @@ template <typename T> __device__ inline T lane_closest_x_(const T c[8], T px, T 
         if (step == T(0)) break;
         T xn = x + step;
         T glim = g0 * (T(1) + T(8) * Lim<T>::eps);
+#pragma nounroll
         for (int k = 0; k < kLaneHalvings; ++k) {
             T fn, dfn, ddfn;
             poly3_(c, xn, fn, dfn, ddfn);
@@ -260,9 +329,10 @@ template <typename T> __device__ inline T lane_closest_x_(const T c[8], T px, T 
 template <typename T>
 __device__ inline void lane_(T x, T y, const T o[8], T eps, Partials<T>& r)
 {
-    T cx = lane_closest_x_(o, x, y);
+    T cx = lane_closest_x_(o[0], o[1], o[2], o[3], x, y);
     T g, dg, ddg;
-    poly3_(o, cx, g, dg, ddg);
+    const T c[4] = {o[0], o[1], o[2], o[3]};
+    poly3_(c, cx, g, dg, ddg);
     T eta = T(1) + dg * ddg + dg * dg - y * ddg;
     if (abs_(eta) < eps) eta = eps;
     T ie = div_(T(2), eta);
@@ -330,13 +400,12 @@ __device__ inline void to_wspace_(T a0, T a1, T b, const Ego<T>& e, const KArgs<
     }
 }
 
+// Ego quantities from the already loaded state / nominal-input vectors.
 template <typename T>
-__device__ inline void load_ego_(const KArgs<T>& p, long long qp, bool qp_only, Ego<T>& e,
+__device__ inline void make_ego_(const KArgs<T>& p, const typename VT<T>::v4& s,
+                                 const typename VT<T>::v2& ur, bool qp_only, Ego<T>& e,
                                  T& ur0, T& ur1, int& bad)
 {
-    using v4 = typename VT<T>::v4;
-    using v2 = typename VT<T>::v2;
-    const v2 ur = reinterpret_cast<const v2*>(p.u_ref)[qp];
     ur0 = ur.x;
     ur1 = ur.y;
     bad = !(finite_(ur0) && finite_(ur1));
@@ -348,7 +417,6 @@ __device__ inline void load_ego_(const KArgs<T>& p, long long qp, bool qp_only, 
         e.un1 = ur1;
         return;
     }
-    const v4 s = reinterpret_cast<const v4*>(p.state)[qp];
     e.x = s.x; e.y = s.y; e.th = s.z; e.v = s.w;
     bad |= !(finite_(s.x) && finite_(s.y) && finite_(s.z) && finite_(s.w));
     sincos_(e.th, &e.sth, &e.cth);
@@ -359,6 +427,18 @@ __device__ inline void load_ego_(const KArgs<T>& p, long long qp, bool qp_only, 
         e.un1 = ur0 * tan_(ur1) * p.inv_L;                       // reference cbf/cbf.py:75
     else
         e.un1 = atan2_(p.lr * tan_(ur1), p.lf + p.lr);       // reference cbf/cbf.py:175
+}
+
+template <typename T>
+__device__ inline void load_ego_(const KArgs<T>& p, long long qp, bool qp_only, Ego<T>& e,
+                                 T& ur0, T& ur1, int& bad)
+{
+    using v4 = typename VT<T>::v4;
+    using v2 = typename VT<T>::v2;
+    const v2 ur = reinterpret_cast<const v2*>(p.u_ref)[qp];
+    v4 s = v4{T(0), T(0), T(0), T(0)};
+    if (!qp_only) s = reinterpret_cast<const v4*>(p.state)[qp];
+    make_ego_(p, s, ur, qp_only, e, ur0, ur1, bad);
 }
 
 template <typename T>
@@ -397,119 +477,105 @@ __global__ __launch_bounds__(kBlock) void k_group(const KArgs<T> p)
     const int g = (int)(gid % G);
     if (qp >= p.A) return;  // groups are lane-aligned: a whole group leaves together
 
+    using v2 = typename VT<T>::v2;
     const int M = p.M;
-    const bool shared = (p.flags & SCCBF_FLAG_OBS_SHARED) != 0;
+    const bool shared = !QP_ONLY && (p.flags & SCCBF_FLAG_OBS_SHARED) != 0;
     const bool type_pa = (p.flags & SCCBF_FLAG_TYPE_PER_AGENT) != 0;
     const v4* obs4 = reinterpret_cast<const v4*>(p.obs);
 
-    // issue every load of this lane before any arithmetic
+    // Every load of this lane is issued up front, in the order the arithmetic consumes
+    // them (ego first, then slot by slot), as straight-line code: slots past M re-read
+    // slot M-1 and are turned into empty rows afterwards.
+    const v2 urv = reinterpret_cast<const v2*>(p.u_ref)[qp];
+    v4 sv = v4{T(0), T(0), T(0), T(0)};
+    if (!QP_ONLY) sv = reinterpret_cast<const v4*>(p.state)[qp];
+    const long long plane = shared ? 1 : p.A;       // distance between the 4-vectors of a slot
+    const long long aoff = shared ? 0 : qp;
+    const long long tstr = type_pa ? p.A : 1, toff = type_pa ? qp : 0;
     v4 oa[RPL], ob[RPL];
     int ty[RPL];
 #pragma unroll
     for (int r = 0; r < RPL; ++r) {
         const int m = r * G + g;
-        ty[r] = SCCBF_OBS_EMPTY;
-        oa[r] = v4{T(0), T(0), T(-1), T(0)};
-        ob[r] = v4{T(0), T(0), T(0), T(0)};
-        if (m < M) {
-            if (QP_ONLY) {
-                oa[r] = obs4[(long long)m * p.A + qp];
-                ty[r] = 0;
-            } else {
-                const long long i0 = shared ? (long long)m * 2 : (long long)m * 2 * p.A + qp;
-                oa[r] = obs4[i0];
-                ob[r] = obs4[i0 + (shared ? 1 : p.A)];
-                ty[r] = type_pa ? p.obs_type[(long long)m * p.A + qp] : p.obs_type[m];
-            }
+        const int mm = m < M ? m : M - 1;
+        ty[r] = 0;
+        // keep the issue order (the vmcnt counter retires loads in order, so the order
+        // decides how early each row's arithmetic may start)
+        __builtin_amdgcn_sched_barrier(0);
+        if (QP_ONLY) {  // the host never launches this kernel with M = 0
+            oa[r] = obs4[(long long)mm * p.A + qp];
+            ob[r] = v4{T(0), T(0), T(0), T(0)};
+        } else {
+            const long long i0 = (long long)mm * 2 * plane + aoff;
+            ty[r] = p.obs_type[(long long)mm * tstr + toff];
+            oa[r] = obs4[i0];
+            ob[r] = obs4[i0 + plane];
         }
     }
+    __builtin_amdgcn_sched_barrier(0);
     Ego<T> e;
     T ur0, ur1;
     int bad;
-    load_ego_(p, qp, QP_ONLY, e, ur0, ur1, bad);
+    make_ego_(p, sv, urv, QP_ONLY, e, ur0, ur1, bad);
 
     // rows of this lane, unit normals in w-space
     T at0[RPL], at1[RPL], bt[RPL];
+    T chk = T(0);  // stays 0 while every row is finite (x * 0 is NaN for Inf / NaN)
 #pragma unroll
     for (int r = 0; r < RPL; ++r) {
         const int m = r * G + g;
         T a0, a1, b, h;
         if (QP_ONLY) {
             a0 = oa[r].x; a1 = oa[r].y; b = oa[r].z; h = T(0);
+            if (m >= M) { a0 = T(0); a1 = T(0); b = T(-1); }
         } else {
             const T o[8] = {oa[r].x, oa[r].y, oa[r].z, oa[r].w, ob[r].x, ob[r].y, ob[r].z, ob[r].w};
-            slot_row_(ty[r], o, e, p, a0, a1, b, h);
+            slot_row_(m < M ? ty[r] : SCCBF_OBS_EMPTY, o, e, p, a0, a1, b, h);
             if (p.rows_out && m < M)
                 reinterpret_cast<v4*>(p.rows_out)[(long long)m * p.A + qp] = v4{a0, a1, b, h};
         }
-        bad |= !(finite_(a0) && finite_(a1) && finite_(b));
+        chk += a0 * T(0) + a1 * T(0) + b * T(0);
         to_wspace_(a0, a1, b, e, p, at0[r], at1[r], bt[r]);
     }
-    bad = group_or<G>(bad);
+    bad |= !(chk == T(0));
+    bad = (int)group_or<G>((unsigned)bad);
 
-    T w0 = T(0), w1 = T(0);
-    int st = bad ? SCCBF_STATUS_NONFINITE : SCCBF_STATUS_OPTIMAL;
-    int last = -1;
-    while (st == SCCBF_STATUS_OPTIMAL) {
-        // lowest-index row above `last` that the current optimum violates
-        int first = 0x7fffffff;
-#pragma unroll
-        for (int r = RPL - 1; r >= 0; --r) {
-            const int m = r * G + g;
-            const T lhs = at0[r] * w0 + at1[r] * w1;
-            const T scale = abs_(at0[r] * w0) + abs_(at1[r] * w1) + abs_(bt[r]);
-            if (m > last && lhs - bt[r] < -Lim<T>::viol_tol * scale) first = m;
-        }
-        first = group_imin<G>(first);
-        if (first == 0x7fffffff) break;
-        // fetch that row from its owner lane
-        const int rsel = first / G, owner = first % G;
+    // active-set iteration: take the most violated row, move the optimum onto it
+    Pivot<T> s;
+    s.w0 = T(0); s.w1 = T(0); s.ns = 0;
+    s.sa0[0] = s.sa0[1] = s.sa1[0] = s.sa1[1] = s.sb[0] = s.sb[1] = T(0);
+    s.st = bad ? SCCBF_STATUS_NONFINITE : SCCBF_STATUS_OPTIMAL;
+    for (int it = 0; s.st == SCCBF_STATUS_OPTIMAL; ++it) {
+        unsigned kbest = 0u;
         T c0 = T(0), c1 = T(0), cb = T(0);
 #pragma unroll
-        for (int r = 0; r < RPL; ++r)
-            if (r == rsel) { c0 = at0[r]; c1 = at1[r]; cb = bt[r]; }
-        if (G > 1) {
-            c0 = shfl_(c0, owner, G);
-            c1 = shfl_(c1, owner, G);
-            cb = shfl_(cb, owner, G);
-        }
-        if (c0 == T(0) && c1 == T(0)) {  // 0 . u >= positive
-            st = SCCBF_STATUS_INFEASIBLE;
-            break;
-        }
-        // optimum on the line c . w = cb: w = p + t d, minimise |w| over the earlier rows
-        const T p0 = c0 * cb, p1 = c1 * cb;
-        const T d0 = -c1, d1 = c0;
-        T tlo = -INFINITY, thi = INFINITY;
-        int inf = 0;
-#pragma unroll
         for (int r = 0; r < RPL; ++r) {
-            const int m = r * G + g;
-            const T cs = at0[r] * d0 + at1[r] * d1;
-            const T ee = bt[r] - (at0[r] * p0 + at1[r] * p1);
-            const bool act = (m < first) && !(at0[r] == T(0) && at1[r] == T(0));
-            if (act) {
-                if (abs_(cs) > Lim<T>::par_tol) {
-                    const T t = div_(ee, cs);
-                    if (cs > T(0)) tlo = max_(tlo, t);
-                    else thi = min_(thi, t);
-                } else if (ee > T(1e-6) * (abs_(bt[r]) + abs_(cb)) + Lim<T>::tiny_n2) {
-                    inf = 1;
-                }
+            const T lhs = at0[r] * s.w0 + at1[r] * s.w1;
+            const T viol = bt[r] - lhs;
+            const T scale = abs_(at0[r] * s.w0) + abs_(at1[r] * s.w1) + abs_(bt[r]);
+            // violation in the high bits, (255 - row index) below: max = most violated, ties to
+            // the lowest index; every key of a group is distinct
+            const unsigned key = (viol_bits(viol) & ~0xFFu) | (unsigned)(255 - (r * G + g));
+            if (viol > Lim<T>::viol_tol * scale && key > kbest) {
+                kbest = key; c0 = at0[r]; c1 = at1[r]; cb = bt[r];
             }
         }
-        tlo = group_max<G>(tlo);
-        thi = group_min<G>(thi);
-        inf = group_or<G>(inf);
-        if (inf || tlo > thi + T(1e-6) * (abs_(tlo) + abs_(thi))) {
-            st = SCCBF_STATUS_INFEASIBLE;
+        const unsigned kmax = group_umax<G>(kbest);
+        if (kmax == 0u) break;  // nothing violated: w is the optimum
+        if (it >= 8 * M + 32) {  // no convergence: rows numerically inconsistent
+            s.st = SCCBF_STATUS_INFEASIBLE;
             break;
         }
-        const T t = min_(max_(T(0), tlo), thi);
-        w0 = p0 + t * d0;
-        w1 = p1 + t * d1;
-        last = first;
+        if (G > 1) {
+            const bool mine = kbest == kmax;
+            c0 = group_pick<G>(c0, mine);
+            c1 = group_pick<G>(c1, mine);
+            cb = group_pick<G>(cb, mine);
+        }
+        pivot_onto_(s, c0, c1, cb);
     }
+    const int st = s.st;
+    const T w0 = s.w0, w1 = s.w1;
     if (g == 0) store_result_(p, qp, QP_ONLY, st, w0, w1, e, ur0, ur1);
 }
 
@@ -564,61 +630,30 @@ __global__ __launch_bounds__(WPB * 64) void k_wave(const KArgs<T> p)
     bad = __any(bad);
     __syncthreads();
 
-    T w0 = T(0), w1 = T(0);
-    int st = bad ? SCCBF_STATUS_NONFINITE : SCCBF_STATUS_OPTIMAL;
-    int last = -1;
-    while (st == SCCBF_STATUS_OPTIMAL) {  // wave-uniform loop
-        int first = -1;
-        for (int base = ((last + 1) / 64) * 64; base < M; base += 64) {
-            const int m = base + lane;
-            bool viol = false;
-            if (m < M && m > last) {
-                const T r0 = s_at0[m], r1 = s_at1[m], rb = s_bt[m];
-                const T lhs = r0 * w0 + r1 * w1;
-                const T scale = abs_(r0 * w0) + abs_(r1 * w1) + abs_(rb);
-                viol = lhs - rb < -Lim<T>::viol_tol * scale;
-            }
-            const unsigned long long mask = __ballot(viol);
-            if (mask) {
-                first = base + __builtin_ctzll(mask);
-                break;
-            }
-        }
-        if (first < 0) break;
-        const T c0 = s_at0[first], c1 = s_at1[first], cb = s_bt[first];  // broadcast read
-        if (c0 == T(0) && c1 == T(0)) {
-            st = SCCBF_STATUS_INFEASIBLE;
-            break;
-        }
-        const T p0 = c0 * cb, p1 = c1 * cb;
-        const T d0 = -c1, d1 = c0;
-        T tlo = -INFINITY, thi = INFINITY;
-        int inf = 0;
-        for (int m = lane; m < first; m += 64) {
+    Pivot<T> s;
+    s.w0 = T(0); s.w1 = T(0); s.ns = 0;
+    s.sa0[0] = s.sa0[1] = s.sa1[0] = s.sa1[1] = s.sb[0] = s.sb[1] = T(0);
+    s.st = bad ? SCCBF_STATUS_NONFINITE : SCCBF_STATUS_OPTIMAL;
+    for (int it = 0; s.st == SCCBF_STATUS_OPTIMAL; ++it) {  // wave-uniform loop
+        unsigned kbest = 0u;
+        for (int m = lane; m < M; m += 64) {
             const T r0 = s_at0[m], r1 = s_at1[m], rb = s_bt[m];
-            if (r0 == T(0) && r1 == T(0)) continue;
-            const T cs = r0 * d0 + r1 * d1;
-            const T ee = rb - (r0 * p0 + r1 * p1);
-            if (abs_(cs) > Lim<T>::par_tol) {
-                const T t = div_(ee, cs);
-                if (cs > T(0)) tlo = max_(tlo, t);
-                else thi = min_(thi, t);
-            } else if (ee > T(1e-6) * (abs_(rb) + abs_(cb)) + Lim<T>::tiny_n2) {
-                inf = 1;
-            }
+            const T viol = rb - (r0 * s.w0 + r1 * s.w1);
+            const T scale = abs_(r0 * s.w0) + abs_(r1 * s.w1) + abs_(rb);
+            const unsigned key = (viol_bits(viol) & ~0x3FFu) | (unsigned)(1023 - m);
+            if (viol > Lim<T>::viol_tol * scale && key > kbest) kbest = key;
         }
-        tlo = group_max<64>(tlo);
-        thi = group_min<64>(thi);
-        inf = __any(inf);
-        if (inf || tlo > thi + T(1e-6) * (abs_(tlo) + abs_(thi))) {
-            st = SCCBF_STATUS_INFEASIBLE;
+        const unsigned kmax = group_umax<64>(kbest);
+        if (kmax == 0u) break;
+        if (it >= 8 * M + 32) {
+            s.st = SCCBF_STATUS_INFEASIBLE;
             break;
         }
-        const T t = min_(max_(T(0), tlo), thi);
-        w0 = p0 + t * d0;
-        w1 = p1 + t * d1;
-        last = first;
+        const int sel = 1023 - (int)(kmax & 0x3FFu);
+        pivot_onto_(s, s_at0[sel], s_at1[sel], s_bt[sel]);  // broadcast reads
     }
+    const int st = s.st;
+    const T w0 = s.w0, w1 = s.w1;
     if (lane == 0 && live) store_result_(p, qp, QP_ONLY, st, w0, w1, e, ur0, ur1);
 }
 
@@ -654,6 +689,24 @@ __global__ __launch_bounds__(kBlock) void k_partials(const KArgs<T> p)
     v4* out = reinterpret_cast<v4*>(p.rows_out);
     out[(long long)m * 2 * p.A + a] = v4{d.h, d.hx, d.hy, d.hth};
     out[(long long)m * 2 * p.A + p.A + a] = v4{d.hv, d.ht, T(0), T(0)};
+}
+
+// ----------------------------------------- no rows at all: the nominal input is optimal
+template <typename T, bool QP_ONLY>
+__global__ __launch_bounds__(kBlock) void k_passthrough(const KArgs<T> p)
+{
+    using v4 = typename VT<T>::v4;
+    using v2 = typename VT<T>::v2;
+    const long long a = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (a >= p.A) return;
+    const v2 ur = reinterpret_cast<const v2*>(p.u_ref)[a];
+    bool ok = finite_(ur.x) && finite_(ur.y);
+    if (!QP_ONLY) {
+        const v4 s = reinterpret_cast<const v4*>(p.state)[a];
+        ok = ok && finite_(s.x) && finite_(s.y) && finite_(s.z) && finite_(s.w);
+    }
+    reinterpret_cast<v2*>(p.u_out)[a] = ur;
+    p.status[a] = ok ? SCCBF_STATUS_OPTIMAL : SCCBF_STATUS_NONFINITE;
 }
 
 // ------------------------------------------------------------------- host side
@@ -739,9 +792,14 @@ int dispatch(const sccbf_params* sp, KArgs<T>& k, void* stream)
 {
     if (k.A == 0) return SCCBF_OK;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (k.M == 0) {
+        const long long blocks = (k.A + kBlock - 1) / kBlock;
+        if (blocks > 0x7fffffffLL) return SCCBF_ERR_ARG;
+        hipLaunchKernelGGL((k_passthrough<T, QP_ONLY>), dim3((unsigned)blocks), dim3(kBlock), 0, s, k);
+        return hipGetLastError() == hipSuccess ? SCCBF_OK : SCCBF_ERR_LAUNCH;
+    }
     int lanes = sp->lanes_per_qp;
     if (lanes == 0) lanes = auto_lanes(k.A, k.M);
-    if (k.M == 0) lanes = 1;
     switch (lanes) {
     case 1: return launch_group_rpl<T, QP_ONLY, 1>(k, s);
     case 2: return launch_group_rpl<T, QP_ONLY, 2>(k, s);

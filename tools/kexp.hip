@@ -1,0 +1,184 @@
+// kexp.hip - stand-alone timing experiments for the filter kernels (not part of the library).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -o tools/kexp tools/kexp.hip && tools/kexp
+// Includes the library source to reuse its device code; kernels here ablate stages.
+#include "../sccav_cbf_amd/csrc/sccbf.hip"
+
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+
+namespace {
+
+// K0: ideal streaming read of the same byte count, one float4 per lane per step
+__global__ __launch_bounds__(256) void k_stream(const float4* __restrict__ in, long long n4, float* out)
+{
+    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long stride = (long long)gridDim.x * 256;
+    float acc = 0.f;
+    for (; i < n4; i += stride) {
+        float4 v = in[i];
+        acc += v.x + v.y + v.z + v.w;
+    }
+    if (acc == 123.456f) out[0] = acc;
+}
+
+// K1: the filter's load pattern, no arithmetic beyond a sum
+template <int G, int RPL>
+__global__ __launch_bounds__(256) void k_loadonly(const KArgs<float> p)
+{
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long qp = gid / G;
+    const int g = (int)(gid % G);
+    if (qp >= p.A) return;
+    const float4* obs4 = reinterpret_cast<const float4*>(p.obs);
+    float4 oa[RPL], ob[RPL];
+#pragma unroll
+    for (int r = 0; r < RPL; ++r) {
+        const int m = r * G + g;
+        const long long i0 = (long long)m * 2 * p.A + qp;
+        oa[r] = obs4[i0];
+        ob[r] = obs4[i0 + p.A];
+    }
+    const float4 s = reinterpret_cast<const float4*>(p.state)[qp];
+    const float2 ur = reinterpret_cast<const float2*>(p.u_ref)[qp];
+    float acc = s.x + s.y + s.z + s.w + ur.x + ur.y;
+#pragma unroll
+    for (int r = 0; r < RPL; ++r) acc += oa[r].x + oa[r].y + oa[r].z + oa[r].w + ob[r].x + ob[r].y + ob[r].z + ob[r].w;
+    acc = __uint_as_float(group_umax<G>(__float_as_uint(acc)));
+    if (g == 0) {
+        reinterpret_cast<float2*>(p.u_out)[qp] = float2{acc, acc};
+        p.status[qp] = 0;
+    }
+}
+
+// K2: loads + rows (barriers, Lie derivatives, w-space), no QP loop
+template <int G, int RPL>
+__global__ __launch_bounds__(256) void k_rowsonly(const KArgs<float> p)
+{
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long qp = gid / G;
+    const int g = (int)(gid % G);
+    if (qp >= p.A) return;
+    const float4* obs4 = reinterpret_cast<const float4*>(p.obs);
+    float4 oa[RPL], ob[RPL];
+    int ty[RPL];
+#pragma unroll
+    for (int r = 0; r < RPL; ++r) {
+        const int m = r * G + g;
+        const long long i0 = (long long)m * 2 * p.A + qp;
+        oa[r] = obs4[i0];
+        ob[r] = obs4[i0 + p.A];
+        ty[r] = p.obs_type[m];
+    }
+    Ego<float> e;
+    float ur0, ur1;
+    int bad;
+    load_ego_(p, qp, false, e, ur0, ur1, bad);
+    float acc = 0.f;
+#pragma unroll
+    for (int r = 0; r < RPL; ++r) {
+        float a0, a1, b, h;
+        const float o[8] = {oa[r].x, oa[r].y, oa[r].z, oa[r].w, ob[r].x, ob[r].y, ob[r].z, ob[r].w};
+        slot_row_(ty[r], o, e, p, a0, a1, b, h);
+        float t0, t1, tb;
+        to_wspace_(a0, a1, b, e, p, t0, t1, tb);
+        acc += t0 + t1 + tb;
+    }
+    acc = __uint_as_float(group_umax<G>(__float_as_uint(acc)));
+    if (g == 0) store_result_(p, qp, false, 0, acc, acc, e, ur0, ur1);
+}
+
+struct Batch {
+    float *state, *u_ref, *obs, *u_out;
+    uint8_t* type;
+    int* status;
+};
+
+template <typename F> float time_it(F launch, int iters, int ring)
+{
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    for (int i = 0; i < 2 * ring; ++i) launch(i % ring);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0, 0));
+    for (int i = 0; i < iters; ++i) launch(i % ring);
+    CK(hipEventRecord(e1, 0));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    return ms / iters * 1e3f;  // us
+}
+
+}  // namespace
+
+int main(int argc, char** argv)
+{
+    const long long A = argc > 1 ? atoll(argv[1]) : 65536;
+    const int M = 16, RING = argc > 2 ? atoi(argv[2]) : 10, ITERS = 400;
+    std::mt19937 rng(1);
+    std::uniform_real_distribution<float> U(-1.f, 1.f);
+    std::vector<Batch> ring(RING);
+    std::vector<float> hs(A * 4), hu(A * 2), ho((size_t)M * 2 * A * 4);
+    std::vector<uint8_t> ht(M);
+    for (int m = 0; m < M; ++m) ht[m] = m < 8 ? 0 : 1;
+    for (int b = 0; b < RING; ++b) {
+        for (long long a = 0; a < A; ++a) {
+            hs[4 * a] = 50 * U(rng); hs[4 * a + 1] = 50 * U(rng); hs[4 * a + 2] = 3.14f * U(rng); hs[4 * a + 3] = 7.5f + 7.5f * U(rng);
+            hu[2 * a] = 8.3f - hs[4 * a + 3]; hu[2 * a + 1] = 0.5f * U(rng);
+        }
+        for (int m = 0; m < M; ++m)
+            for (long long a = 0; a < A; ++a) {
+                float rg = 37.5f + 22.5f * U(rng), br = 3.14f * U(rng);
+                float* o0 = &ho[(((size_t)m * 2 + 0) * A + a) * 4];
+                float* o1 = &ho[(((size_t)m * 2 + 1) * A + a) * 4];
+                o0[0] = hs[4 * a] + rg * cosf(br); o0[1] = hs[4 * a + 1] + rg * sinf(br);
+                if (m < 8) { o0[2] = 11 + 9 * U(rng); o0[3] = 5.5f + 4.5f * U(rng); o1[0] = 3.14f * U(rng); o1[1] = 2 * U(rng); o1[2] = 2 * U(rng); o1[3] = 0; }
+                else { o0[2] = 3.14f * U(rng); o0[3] = 2.5f + 2.5f * U(rng); o1[0] = 4.5f + 2 * U(rng); o1[1] = 0; o1[2] = 0; o1[3] = 0; }
+            }
+        Batch& B = ring[b];
+        CK(hipMalloc(&B.state, A * 16)); CK(hipMalloc(&B.u_ref, A * 8)); CK(hipMalloc(&B.obs, (size_t)M * 2 * A * 16));
+        CK(hipMalloc(&B.u_out, A * 8)); CK(hipMalloc(&B.status, A * 4)); CK(hipMalloc(&B.type, M));
+        CK(hipMemcpy(B.state, hs.data(), A * 16, hipMemcpyHostToDevice));
+        CK(hipMemcpy(B.u_ref, hu.data(), A * 8, hipMemcpyHostToDevice));
+        CK(hipMemcpy(B.obs, ho.data(), (size_t)M * 2 * A * 16, hipMemcpyHostToDevice));
+        CK(hipMemcpy(B.type, ht.data(), M, hipMemcpyHostToDevice));
+    }
+    sccbf_params sp;
+    sccbf_default_params(&sp);
+    sp.R[0] = sp.R[3] = 0.5;
+    KArgs<float> k;
+    fill_args<float>(&sp, A, M, k);
+    const double bytes = (double)A * (4.0 * (4 + 2 + 8 * M + 2) + 4);
+    auto report = [&](const char* name, float us) {
+        printf("%-28s %8.2f us  %7.1f GB/s  (%.1f%% of 8 TB/s)\n", name, us, bytes / us * 1e-3, bytes / us * 1e-3 / 80.0);
+        fflush(stdout);
+    };
+    auto setk = [&](int b) {
+        k.state = ring[b].state; k.u_ref = ring[b].u_ref; k.obs = ring[b].obs; k.obs_type = ring[b].type;
+        k.u_out = ring[b].u_out; k.status = ring[b].status; k.rows_out = nullptr;
+    };
+    printf("A=%lld M=%d ring=%d  algorithmic bytes/launch %.0f\n", A, M, RING, bytes);
+    for (int blocks : {256, 512, 1024, 2048, 4096}) {
+        char nm[64];
+        snprintf(nm, sizeof nm, "stream (obs only) grid %d", blocks);
+        report(nm, time_it([&](int b) { hipLaunchKernelGGL(k_stream, dim3(blocks), dim3(256), 0, 0, (const float4*)ring[b].obs, (long long)M * 2 * A, ring[b].u_out); }, ITERS, RING));
+    }
+#define RUN_G(G, RPL) \
+    report("loadonly G=" #G, time_it([&](int b) { setk(b); hipLaunchKernelGGL((k_loadonly<G, RPL>), dim3((unsigned)((A * G + 255) / 256)), dim3(256), 0, 0, k); }, ITERS, RING)); \
+    report("rowsonly G=" #G, time_it([&](int b) { setk(b); hipLaunchKernelGGL((k_rowsonly<G, RPL>), dim3((unsigned)((A * G + 255) / 256)), dim3(256), 0, 0, k); }, ITERS, RING)); \
+    report("full     G=" #G, time_it([&](int b) { setk(b); hipLaunchKernelGGL((k_group<float, G, RPL, false>), dim3((unsigned)((A * G + 255) / 256)), dim3(256), 0, 0, k); }, ITERS, RING));
+    RUN_G(1, 16)
+    RUN_G(2, 8)
+    RUN_G(4, 4)
+    RUN_G(8, 2)
+    RUN_G(16, 1)
+    CK(hipDeviceSynchronize());
+    int st[8];
+    CK(hipMemcpy(st, ring[0].status, sizeof st, hipMemcpyDeviceToHost));
+    printf("status[0..7] = %d %d %d %d %d %d %d %d\n", st[0], st[1], st[2], st[3], st[4], st[5], st[6], st[7]);
+    return 0;
+}
