@@ -43,6 +43,7 @@ template <> struct VT<double> {
 
 template <typename T> struct KArgs {
     T alpha, lr, lf, L, inv_lr, inv_L;
+    T k_in, k_out;  // lr / (lf + lr) and its inverse: the steering <-> slip maps
     T l10, inv_l00, inv_l11;  // Cholesky factor of R
     T zero_tol;
     int dynamics;
@@ -88,6 +89,27 @@ __device__ inline float tan_(float x)
     return s * __builtin_amdgcn_rcpf(c);
 }
 __device__ inline double tan_(double x) { return tan(x); }
+// atan for fp32: t P(t^2) on [0, 1] (Chebyshev fit, 1.1e-7 absolute), 1/t reflection above 1
+__device__ inline float atan_(float z)
+{
+    const float az = fabsf(z);
+    const bool big = az > 1.0f;
+    const float t = big ? __builtin_amdgcn_rcpf(az) : az;
+    const float s = t * t;
+    float q = 0.0027662834618240595f;
+    q = fmaf(q, s, -0.015731249004602432f);
+    q = fmaf(q, s, 0.04213762283325195f);
+    q = fmaf(q, s, -0.07456854730844498f);
+    q = fmaf(q, s, 0.10618370771408081f);
+    q = fmaf(q, s, -0.14197798073291779f);
+    q = fmaf(q, s, 0.1999187171459198f);
+    q = fmaf(q, s, -0.333330363035202f);
+    q = fmaf(q, s, 1.0f);
+    float r = t * q;
+    r = big ? 1.5707963267948966f - r : r;
+    return copysignf(r, z);
+}
+__device__ inline double atan_(double z) { return atan(z); }
 __device__ inline float atan2_(float y, float x) { return atan2f(y, x); }
 __device__ inline double atan2_(double y, double x) { return atan2(y, x); }
 __device__ inline float abs_(float x) { return fabsf(x); }
@@ -170,45 +192,48 @@ template <typename T> struct Pivot {
 // Move the optimum onto the violated row c . w = cb (unit normal c): the new optimum of
 // {active rows} + {this row} lies on that line; along it, w = p + t d, the active rows
 // bound t and the point nearest to the origin inside the bounds is taken.  The row that
-// clamps t (if any) stays active, the other one is released.
-template <typename T> __device__ inline void pivot_onto_(Pivot<T>& s, T c0, T c1, T cb)
+// clamps t (if any) stays active, the other one is released.  Straight-line code: every
+// lane evaluates it and `go` selects which lanes commit the result.
+template <typename T> __device__ inline void pivot_onto_(Pivot<T>& s, T c0, T c1, T cb, bool go)
 {
-    if (c0 == T(0) && c1 == T(0)) {  // 0 . u >= positive
-        s.st = SCCBF_STATUS_INFEASIBLE;
-        return;
-    }
+    constexpr T kInf = INFINITY;
+    const bool zero_row = (c0 == T(0)) & (c1 == T(0));  // 0 . u >= positive
     const T p0 = c0 * cb, p1 = c1 * cb;
     const T d0 = -c1, d1 = c0;
-    T tlo = -INFINITY, thi = INFINITY;
-    int jlo = -1, jhi = -1;
-    bool inf = false;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        if (j < s.ns) {
-            const T cs = s.sa0[j] * d0 + s.sa1[j] * d1;
-            const T ee = s.sb[j] - (s.sa0[j] * p0 + s.sa1[j] * p1);
-            if (abs_(cs) > Lim<T>::par_tol) {
-                const T t = div_(ee, cs);
-                if (cs > T(0)) { if (t > tlo) { tlo = t; jlo = j; } }
-                else { if (t < thi) { thi = t; jhi = j; } }
-            } else if (ee > Lim<T>::feas_tol * (abs_(s.sb[j]) + abs_(cb)) + Lim<T>::tiny_n2) {
-                inf = true;  // parallel rows facing each other with a gap
-            }
-        }
-    }
-    if (inf || tlo > thi + Lim<T>::feas_tol * (abs_(tlo) + abs_(thi))) {
-        s.st = SCCBF_STATUS_INFEASIBLE;
-        return;
-    }
-    T t = T(0);
-    int keep = -1;
-    if (tlo > T(0)) { t = tlo; keep = jlo; }
-    else if (thi < T(0)) { t = thi; keep = jhi; }
-    s.w0 = p0 + t * d0;
-    s.w1 = p1 + t * d1;
-    if (keep == 0) { s.sa0[1] = s.sa0[0]; s.sa1[1] = s.sa1[0]; s.sb[1] = s.sb[0]; }  // keep == 1 stays put
-    s.sa0[0] = c0; s.sa1[0] = c1; s.sb[0] = cb;
-    s.ns = keep >= 0 ? 2 : 1;
+    const bool v0 = s.ns > 0, v1 = s.ns > 1;
+    const T cs0 = s.sa0[0] * d0 + s.sa1[0] * d1, cs1 = s.sa0[1] * d0 + s.sa1[1] * d1;
+    const T ee0 = s.sb[0] - (s.sa0[0] * p0 + s.sa1[0] * p1);
+    const T ee1 = s.sb[1] - (s.sa0[1] * p0 + s.sa1[1] * p1);
+    const bool np0 = abs_(cs0) > Lim<T>::par_tol, np1 = abs_(cs1) > Lim<T>::par_tol;
+    const T t0 = div_(ee0, cs0), t1 = div_(ee1, cs1);  // garbage for parallel / unused slots
+    const bool lo0 = v0 & np0 & (cs0 > T(0)), lo1 = v1 & np1 & (cs1 > T(0));
+    const bool hi0 = v0 & np0 & !(cs0 > T(0)), hi1 = v1 & np1 & !(cs1 > T(0));
+    const T tl0 = lo0 ? t0 : -kInf, tl1 = lo1 ? t1 : -kInf;
+    const T th0 = hi0 ? t0 : kInf, th1 = hi1 ? t1 : kInf;
+    const bool l1 = tl1 > tl0, h1 = th1 < th0;
+    const T tlo = l1 ? tl1 : tl0, thi = h1 ? th1 : th0;
+    // parallel rows facing each other with a gap, or crossing bounds: no common point
+    bool inf = (v0 & !np0 & (ee0 > Lim<T>::feas_tol * (abs_(s.sb[0]) + abs_(cb)) + Lim<T>::tiny_n2)) |
+               (v1 & !np1 & (ee1 > Lim<T>::feas_tol * (abs_(s.sb[1]) + abs_(cb)) + Lim<T>::tiny_n2));
+    inf |= tlo > thi + Lim<T>::feas_tol * (abs_(tlo) + abs_(thi));
+    const bool bad = zero_row | inf;
+    const bool uselo = tlo > T(0);
+    const bool usehi = !uselo & (thi < T(0));
+    const T t = uselo ? tlo : (usehi ? thi : T(0));
+    const bool keepany = uselo | usehi;
+    const bool keep1 = uselo ? l1 : h1;  // the clamping row sits in slot 1 (else slot 0)
+    const bool upd = go & !bad;
+    const bool mv = upd & keepany & !keep1;
+    s.w0 = upd ? p0 + t * d0 : s.w0;
+    s.w1 = upd ? p1 + t * d1 : s.w1;
+    s.sa0[1] = mv ? s.sa0[0] : s.sa0[1];
+    s.sa1[1] = mv ? s.sa1[0] : s.sa1[1];
+    s.sb[1] = mv ? s.sb[0] : s.sb[1];
+    s.sa0[0] = upd ? c0 : s.sa0[0];
+    s.sa1[0] = upd ? c1 : s.sa1[0];
+    s.sb[0] = upd ? cb : s.sb[0];
+    s.ns = upd ? (keepany ? 2 : 1) : s.ns;
+    s.st = (go & bad) ? SCCBF_STATUS_INFEASIBLE : s.st;
 }
 
 // --------------------------------------------------------------------- barriers
@@ -426,7 +451,7 @@ __device__ inline void make_ego_(const KArgs<T>& p, const typename VT<T>::v4& s,
     else if (p.dynamics == SCCBF_DYN_KBM)
         e.un1 = ur0 * tan_(ur1) * p.inv_L;                       // reference cbf/cbf.py:75
     else
-        e.un1 = atan2_(p.lr * tan_(ur1), p.lf + p.lr);       // reference cbf/cbf.py:175
+        e.un1 = atan_(tan_(ur1) * p.k_in);   // atan2(lr tan(delta), lf + lr), lf + lr > 0: reference cbf/cbf.py:175
 }
 
 template <typename T>
@@ -461,7 +486,7 @@ __device__ inline void store_result_(const KArgs<T>& p, long long qp, bool qp_on
         else if (p.dynamics == SCCBF_DYN_KBM)
             out.y = atan2_(u1 * p.L, ur0);                    // reference cbf/cbf.py:109
         else
-            out.y = atan2_((p.lf + p.lr) * tan_(u1), p.lr);   // reference cbf/cbf.py:216
+            out.y = atan_(tan_(u1) * p.k_out);  // atan2((lf + lr) tan(beta), lr), lr > 0: reference cbf/cbf.py:216
     }
     reinterpret_cast<v2*>(p.u_out)[qp] = out;
     p.status[qp] = st;
@@ -545,25 +570,32 @@ __global__ __launch_bounds__(kBlock) void k_group(const KArgs<T> p)
     s.w0 = T(0); s.w1 = T(0); s.ns = 0;
     s.sa0[0] = s.sa0[1] = s.sa1[0] = s.sa1[1] = s.sb[0] = s.sb[1] = T(0);
     s.st = bad ? SCCBF_STATUS_NONFINITE : SCCBF_STATUS_OPTIMAL;
-    for (int it = 0; s.st == SCCBF_STATUS_OPTIMAL; ++it) {
+    unsigned idx[RPL];  // 255 - row index: ties in violation go to the lowest index
+#pragma unroll
+    for (int r = 0; r < RPL; ++r) idx[r] = (unsigned)(255 - (r * G + g));
+    const int cap = 8 * M + 32;
+    for (int it = 0;; ++it) {  // wave-uniform trip count, lanes commit under `go`
+        // rows are unit-normal, so bt - a.w is a distance; below this it is rounding
+        const T thr = Lim<T>::viol_tol * (abs_(s.w0) + abs_(s.w1)) + Lim<T>::tiny_n2;
         unsigned kbest = 0u;
         T c0 = T(0), c1 = T(0), cb = T(0);
 #pragma unroll
         for (int r = 0; r < RPL; ++r) {
-            const T lhs = at0[r] * s.w0 + at1[r] * s.w1;
-            const T viol = bt[r] - lhs;
-            const T scale = abs_(at0[r] * s.w0) + abs_(at1[r] * s.w1) + abs_(bt[r]);
-            // violation in the high bits, (255 - row index) below: max = most violated, ties to
-            // the lowest index; every key of a group is distinct
-            const unsigned key = (viol_bits(viol) & ~0xFFu) | (unsigned)(255 - (r * G + g));
-            if (viol > Lim<T>::viol_tol * scale && key > kbest) {
-                kbest = key; c0 = at0[r]; c1 = at1[r]; cb = bt[r];
-            }
+            const T viol = bt[r] - (at0[r] * s.w0 + at1[r] * s.w1);
+            // violation in the high bits, idx below: the max is the most violated row and
+            // every key of a group is distinct
+            const unsigned key = viol > thr ? ((viol_bits(viol) & ~0xFFu) | idx[r]) : 0u;
+            const bool better = key > kbest;
+            kbest = better ? key : kbest;
+            c0 = better ? at0[r] : c0;
+            c1 = better ? at1[r] : c1;
+            cb = better ? bt[r] : cb;
         }
         const unsigned kmax = group_umax<G>(kbest);
-        if (kmax == 0u) break;  // nothing violated: w is the optimum
-        if (it >= 8 * M + 32) {  // no convergence: rows numerically inconsistent
-            s.st = SCCBF_STATUS_INFEASIBLE;
+        const bool go = (s.st == SCCBF_STATUS_OPTIMAL) & (kmax != 0u);
+        if (!__any(go)) break;  // every group of the wave is done
+        if (it >= cap) {        // no convergence: rows numerically inconsistent
+            s.st = go ? SCCBF_STATUS_INFEASIBLE : s.st;
             break;
         }
         if (G > 1) {
@@ -572,7 +604,7 @@ __global__ __launch_bounds__(kBlock) void k_group(const KArgs<T> p)
             c1 = group_pick<G>(c1, mine);
             cb = group_pick<G>(cb, mine);
         }
-        pivot_onto_(s, c0, c1, cb);
+        pivot_onto_(s, c0, c1, cb, go);
     }
     const int st = s.st;
     const T w0 = s.w0, w1 = s.w1;
@@ -634,23 +666,24 @@ __global__ __launch_bounds__(WPB * 64) void k_wave(const KArgs<T> p)
     s.w0 = T(0); s.w1 = T(0); s.ns = 0;
     s.sa0[0] = s.sa0[1] = s.sa1[0] = s.sa1[1] = s.sb[0] = s.sb[1] = T(0);
     s.st = bad ? SCCBF_STATUS_NONFINITE : SCCBF_STATUS_OPTIMAL;
-    for (int it = 0; s.st == SCCBF_STATUS_OPTIMAL; ++it) {  // wave-uniform loop
+    const int cap = 8 * M + 32;
+    for (int it = 0;; ++it) {  // wave-uniform loop
+        const T thr = Lim<T>::viol_tol * (abs_(s.w0) + abs_(s.w1)) + Lim<T>::tiny_n2;
         unsigned kbest = 0u;
         for (int m = lane; m < M; m += 64) {
-            const T r0 = s_at0[m], r1 = s_at1[m], rb = s_bt[m];
-            const T viol = rb - (r0 * s.w0 + r1 * s.w1);
-            const T scale = abs_(r0 * s.w0) + abs_(r1 * s.w1) + abs_(rb);
-            const unsigned key = (viol_bits(viol) & ~0x3FFu) | (unsigned)(1023 - m);
-            if (viol > Lim<T>::viol_tol * scale && key > kbest) kbest = key;
+            const T viol = s_bt[m] - (s_at0[m] * s.w0 + s_at1[m] * s.w1);
+            const unsigned key = viol > thr ? ((viol_bits(viol) & ~0x3FFu) | (unsigned)(1023 - m)) : 0u;
+            kbest = key > kbest ? key : kbest;
         }
         const unsigned kmax = group_umax<64>(kbest);
-        if (kmax == 0u) break;
-        if (it >= 8 * M + 32) {
+        const bool go = (s.st == SCCBF_STATUS_OPTIMAL) & (kmax != 0u);
+        if (!go) break;
+        if (it >= cap) {
             s.st = SCCBF_STATUS_INFEASIBLE;
             break;
         }
         const int sel = 1023 - (int)(kmax & 0x3FFu);
-        pivot_onto_(s, s_at0[sel], s_at1[sel], s_bt[sel]);  // broadcast reads
+        pivot_onto_(s, s_at0[sel], s_at1[sel], s_bt[sel], true);  // broadcast reads
     }
     const int st = s.st;
     const T w0 = s.w0, w1 = s.w1;
@@ -726,6 +759,7 @@ int fill_args(const sccbf_params* sp, int64_t A, int32_t M, KArgs<T>& k)
     if (sp->dynamics == SCCBF_DYN_KBM && !(sp->L > 0.0)) return SCCBF_ERR_ARG;
     k.alpha = (T)sp->alpha; k.lr = (T)sp->lr; k.lf = (T)sp->lf; k.L = (T)sp->L;
     k.inv_lr = (T)(1.0 / sp->lr); k.inv_L = (T)(1.0 / sp->L);
+    k.k_in = (T)(sp->lr / (sp->lf + sp->lr)); k.k_out = (T)((sp->lf + sp->lr) / sp->lr);
     k.l10 = (T)l10; k.inv_l00 = (T)(1.0 / l00); k.inv_l11 = (T)(1.0 / l11);
     k.zero_tol = (T)sp->zero_tol;
     k.dynamics = sp->dynamics;

@@ -25,8 +25,10 @@ __global__ __launch_bounds__(256) void k_stream(const float4* __restrict__ in, l
     if (acc == 123.456f) out[0] = acc;
 }
 
-// K1: the filter's load pattern, no arithmetic beyond a sum
-template <int G, int RPL>
+// K1: the filter's load pattern, no arithmetic beyond a sum.
+// VAR 0: as the library kernel; 1: lane g owns slots g*RPL..g*RPL+RPL-1; 2: no ego loads;
+// 3: result stored by one lane per wave only; 4: 2 + 3
+template <int G, int RPL, int VAR>
 __global__ __launch_bounds__(256) void k_loadonly(const KArgs<float> p)
 {
     const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -37,18 +39,23 @@ __global__ __launch_bounds__(256) void k_loadonly(const KArgs<float> p)
     float4 oa[RPL], ob[RPL];
 #pragma unroll
     for (int r = 0; r < RPL; ++r) {
-        const int m = r * G + g;
+        const int m = VAR == 1 ? g * RPL + r : r * G + g;
         const long long i0 = (long long)m * 2 * p.A + qp;
         oa[r] = obs4[i0];
         ob[r] = obs4[i0 + p.A];
     }
-    const float4 s = reinterpret_cast<const float4*>(p.state)[qp];
-    const float2 ur = reinterpret_cast<const float2*>(p.u_ref)[qp];
-    float acc = s.x + s.y + s.z + s.w + ur.x + ur.y;
+    float acc = 0.f;
+    if (VAR != 2 && VAR != 4) {
+        const float4 s = reinterpret_cast<const float4*>(p.state)[qp];
+        const float2 ur = reinterpret_cast<const float2*>(p.u_ref)[qp];
+        acc = s.x + s.y + s.z + s.w + ur.x + ur.y;
+    }
 #pragma unroll
     for (int r = 0; r < RPL; ++r) acc += oa[r].x + oa[r].y + oa[r].z + oa[r].w + ob[r].x + ob[r].y + ob[r].z + ob[r].w;
     acc = __uint_as_float(group_umax<G>(__float_as_uint(acc)));
-    if (g == 0) {
+    if (VAR >= 3) {
+        if ((threadIdx.x & 63) == 0) { reinterpret_cast<float2*>(p.u_out)[qp] = float2{acc, acc}; p.status[qp] = 0; }
+    } else if (g == 0) {
         reinterpret_cast<float2*>(p.u_out)[qp] = float2{acc, acc};
         p.status[qp] = 0;
     }
@@ -168,7 +175,11 @@ int main(int argc, char** argv)
         report(nm, time_it([&](int b) { hipLaunchKernelGGL(k_stream, dim3(blocks), dim3(256), 0, 0, (const float4*)ring[b].obs, (long long)M * 2 * A, ring[b].u_out); }, ITERS, RING));
     }
 #define RUN_G(G, RPL) \
-    report("loadonly G=" #G, time_it([&](int b) { setk(b); hipLaunchKernelGGL((k_loadonly<G, RPL>), dim3((unsigned)((A * G + 255) / 256)), dim3(256), 0, 0, k); }, ITERS, RING)); \
+    report("loadonly G=" #G, time_it([&](int b) { setk(b); hipLaunchKernelGGL((k_loadonly<G, RPL, 0>), dim3((unsigned)((A * G + 255) / 256)), dim3(256), 0, 0, k); }, ITERS, RING)); \
+    report("loadonly G=" #G " slots/lane", time_it([&](int b) { setk(b); hipLaunchKernelGGL((k_loadonly<G, RPL, 1>), dim3((unsigned)((A * G + 255) / 256)), dim3(256), 0, 0, k); }, ITERS, RING)); \
+    report("loadonly G=" #G " no ego", time_it([&](int b) { setk(b); hipLaunchKernelGGL((k_loadonly<G, RPL, 2>), dim3((unsigned)((A * G + 255) / 256)), dim3(256), 0, 0, k); }, ITERS, RING)); \
+    report("loadonly G=" #G " 1 store/wave", time_it([&](int b) { setk(b); hipLaunchKernelGGL((k_loadonly<G, RPL, 3>), dim3((unsigned)((A * G + 255) / 256)), dim3(256), 0, 0, k); }, ITERS, RING)); \
+    report("loadonly G=" #G " no ego, 1 store", time_it([&](int b) { setk(b); hipLaunchKernelGGL((k_loadonly<G, RPL, 4>), dim3((unsigned)((A * G + 255) / 256)), dim3(256), 0, 0, k); }, ITERS, RING)); \
     report("rowsonly G=" #G, time_it([&](int b) { setk(b); hipLaunchKernelGGL((k_rowsonly<G, RPL>), dim3((unsigned)((A * G + 255) / 256)), dim3(256), 0, 0, k); }, ITERS, RING)); \
     report("full     G=" #G, time_it([&](int b) { setk(b); hipLaunchKernelGGL((k_group<float, G, RPL, false>), dim3((unsigned)((A * G + 255) / 256)), dim3(256), 0, 0, k); }, ITERS, RING));
     RUN_G(1, 16)
