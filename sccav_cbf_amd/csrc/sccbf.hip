@@ -27,7 +27,10 @@
 
 namespace {
 
-constexpr int kBlock = 256;
+#ifndef SCCBF_BLOCK
+#define SCCBF_BLOCK 256  // threads per workgroup of the group / passthrough / partials kernels
+#endif
+constexpr int kBlock = SCCBF_BLOCK;
 constexpr int kLaneIters = 32;     // Newton iterations for the lane closest point
 constexpr int kLaneHalvings = 30;  // step halvings per iteration
 

@@ -12,12 +12,20 @@
 
 namespace {
 
-// K0: ideal streaming read of the same byte count, one float4 per lane per step
+// K0: ideal streaming read of the same byte count; U loads of one float4 in flight per lane
+template <int U>
 __global__ __launch_bounds__(256) void k_stream(const float4* __restrict__ in, long long n4, float* out)
 {
     long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     const long long stride = (long long)gridDim.x * 256;
     float acc = 0.f;
+    for (; i + (U - 1) * stride < n4; i += U * stride) {
+        float4 v[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) v[k] = in[i + k * stride];
+#pragma unroll
+        for (int k = 0; k < U; ++k) acc += v[k].x + v[k].y + v[k].z + v[k].w;
+    }
     for (; i < n4; i += stride) {
         float4 v = in[i];
         acc += v.x + v.y + v.z + v.w;
@@ -40,9 +48,18 @@ __global__ __launch_bounds__(256) void k_loadonly(const KArgs<float> p)
 #pragma unroll
     for (int r = 0; r < RPL; ++r) {
         const int m = VAR == 1 ? g * RPL + r : r * G + g;
-        const long long i0 = (long long)m * 2 * p.A + qp;
+        long long i0 = (long long)m * 2 * p.A + qp, i1 = i0 + p.A;
+        if (VAR == 5) {  // slot groups interleaved: one contiguous KiB per wave instruction
+            i0 = ((long long)(r * 2) * p.A + qp) * G + g;
+            i1 = ((long long)(r * 2 + 1) * p.A + qp) * G + g;
+        }
+        if (VAR == 6) {  // tiles of 64 agents: [A/64][M][2][64] float4
+            const long long tb = (qp >> 6) * (long long)(p.M * 2 * 64) + (qp & 63);
+            i0 = tb + (long long)(m * 2) * 64;
+            i1 = i0 + 64;
+        }
         oa[r] = obs4[i0];
-        ob[r] = obs4[i0 + p.A];
+        ob[r] = obs4[i1];
     }
     float acc = 0.f;
     if (VAR != 2 && VAR != 4) {
@@ -171,17 +188,23 @@ int main(int argc, char** argv)
     printf("A=%lld M=%d ring=%d  algorithmic bytes/launch %.0f\n", A, M, RING, bytes);
     for (int blocks : {256, 512, 1024, 2048, 4096}) {
         char nm[64];
-        snprintf(nm, sizeof nm, "stream (obs only) grid %d", blocks);
-        report(nm, time_it([&](int b) { hipLaunchKernelGGL(k_stream, dim3(blocks), dim3(256), 0, 0, (const float4*)ring[b].obs, (long long)M * 2 * A, ring[b].u_out); }, ITERS, RING));
+        snprintf(nm, sizeof nm, "stream U=1 grid %d", blocks);
+        report(nm, time_it([&](int b) { hipLaunchKernelGGL(k_stream<1>, dim3(blocks), dim3(256), 0, 0, (const float4*)ring[b].obs, (long long)M * 2 * A, ring[b].u_out); }, ITERS, RING));
+        snprintf(nm, sizeof nm, "stream U=4 grid %d", blocks);
+        report(nm, time_it([&](int b) { hipLaunchKernelGGL(k_stream<4>, dim3(blocks), dim3(256), 0, 0, (const float4*)ring[b].obs, (long long)M * 2 * A, ring[b].u_out); }, ITERS, RING));
+        snprintf(nm, sizeof nm, "stream U=8 grid %d", blocks);
+        report(nm, time_it([&](int b) { hipLaunchKernelGGL(k_stream<8>, dim3(blocks), dim3(256), 0, 0, (const float4*)ring[b].obs, (long long)M * 2 * A, ring[b].u_out); }, ITERS, RING));
     }
 #define RUN_G(G, RPL) \
     report("loadonly G=" #G, time_it([&](int b) { setk(b); hipLaunchKernelGGL((k_loadonly<G, RPL, 0>), dim3((unsigned)((A * G + 255) / 256)), dim3(256), 0, 0, k); }, ITERS, RING)); \
+    report("loadonly G=" #G " interleaved", time_it([&](int b) { setk(b); hipLaunchKernelGGL((k_loadonly<G, RPL, 5>), dim3((unsigned)((A * G + 255) / 256)), dim3(256), 0, 0, k); }, ITERS, RING)); \
+    report("loadonly G=" #G " tiles64", time_it([&](int b) { setk(b); hipLaunchKernelGGL((k_loadonly<G, RPL, 6>), dim3((unsigned)((A * G + 255) / 256)), dim3(256), 0, 0, k); }, ITERS, RING)); \
     report("loadonly G=" #G " slots/lane", time_it([&](int b) { setk(b); hipLaunchKernelGGL((k_loadonly<G, RPL, 1>), dim3((unsigned)((A * G + 255) / 256)), dim3(256), 0, 0, k); }, ITERS, RING)); \
     report("loadonly G=" #G " no ego", time_it([&](int b) { setk(b); hipLaunchKernelGGL((k_loadonly<G, RPL, 2>), dim3((unsigned)((A * G + 255) / 256)), dim3(256), 0, 0, k); }, ITERS, RING)); \
     report("loadonly G=" #G " 1 store/wave", time_it([&](int b) { setk(b); hipLaunchKernelGGL((k_loadonly<G, RPL, 3>), dim3((unsigned)((A * G + 255) / 256)), dim3(256), 0, 0, k); }, ITERS, RING)); \
     report("loadonly G=" #G " no ego, 1 store", time_it([&](int b) { setk(b); hipLaunchKernelGGL((k_loadonly<G, RPL, 4>), dim3((unsigned)((A * G + 255) / 256)), dim3(256), 0, 0, k); }, ITERS, RING)); \
     report("rowsonly G=" #G, time_it([&](int b) { setk(b); hipLaunchKernelGGL((k_rowsonly<G, RPL>), dim3((unsigned)((A * G + 255) / 256)), dim3(256), 0, 0, k); }, ITERS, RING)); \
-    report("full     G=" #G, time_it([&](int b) { setk(b); hipLaunchKernelGGL((k_group<float, G, RPL, false>), dim3((unsigned)((A * G + 255) / 256)), dim3(256), 0, 0, k); }, ITERS, RING));
+    report("full     G=" #G, time_it([&](int b) { setk(b); hipLaunchKernelGGL((k_group<float, G, RPL, false>), dim3((unsigned)((A * G + kBlock - 1) / kBlock)), dim3(kBlock), 0, 0, k); }, ITERS, RING));
     RUN_G(1, 16)
     RUN_G(2, 8)
     RUN_G(4, 4)
