@@ -141,17 +141,6 @@ def main():
         wall = t1 - t0
         dev_ms = ev0.elapsed_time(ev1)
 
-        # per-launch kernel duration: event pairs around single eager launches
-        per = []
-        for i in range(4 * RING):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(stream)
-            step(i)
-            e1.record(stream)
-            torch.cuda.synchronize()
-            per.append(e0.elapsed_time(e1))
-        per_launch_ms = float(np.median(per))
-
     tw = torch.tensor([wall], dtype=torch.float64, device=device)
     if dist is not None:
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
@@ -185,7 +174,7 @@ def main():
                        "launch": "eager" if graph is None else "hipGraph of %d launches" % RING},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel_ms": kern_ms, "event_pair_ms": per_launch_ms,
+                         "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_launch": abytes},
             "status_counts": {"optimal": int(counts[0]), "infeasible": int(counts[1]),
                               "nonfinite": int(counts[2])},
