@@ -23,7 +23,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from sccav_cbf_amd import scenarios  # noqa: E402
-from sccav_cbf_amd.batched import BatchedCBF  # noqa: E402
+from sccav_cbf_amd.batched import BatchedCBF, planes_to_tiled  # noqa: E402
 
 AGENTS = 65536
 ROWS = 16
@@ -36,16 +36,18 @@ def algorithmic_bytes(A, M, w=4):
     return A * (w * (4 + 2 + 8 * M + 2) + 4)
 
 
-def make_ring(rank, device, n=RING, agents=AGENTS):
+def make_ring(rank, device, n=RING, agents=AGENTS, tiled=True):
     ring = []
     for b in range(n):
         w = scenarios.config4(A=agents, seed=1234 + 4 + 1000 * rank + b)
         t = dict(state=torch.from_numpy(w["state"]).float().to(device),
                  u_ref=torch.from_numpy(w["u_ref"]).float().to(device),
-                 obs=torch.from_numpy(w["obs"]).float().to(device),
+                 obs=torch.from_numpy(w["obs"]).float().to(device),   # (M,2,A,4) planes
                  obs_type=torch.from_numpy(w["obs_type"]).to(device),
                  u_out=torch.empty((agents, 2), dtype=torch.float32, device=device),
                  status=torch.empty((agents,), dtype=torch.int32, device=device))
+        if tiled:   # tiles of 64 agents: (A/64, M, 2, 64, 4)
+            t["obs"] = planes_to_tiled(t["obs"])
         ring.append(t)
     return ring
 
@@ -79,6 +81,7 @@ def main():
     ap.add_argument("--agents", type=int, default=AGENTS)
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
+    ap.add_argument("--planes", action="store_true", help="obstacles as (M,2,A,4) planes instead of 64-agent tiles")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -95,7 +98,7 @@ def main():
 
     A, M = args.agents, ROWS
     flt = BatchedCBF(alpha=1.0, lr=1.45, lf=1.45, R=np.diag([0.5, 0.5]), lanes_per_qp=args.lanes)
-    ring = make_ring(rank, device, agents=A)
+    ring = make_ring(rank, device, agents=A, tiled=not args.planes)
 
     def step(i):
         b = ring[i % RING]
@@ -171,6 +174,7 @@ def main():
             "config": {"workload": "C4: %d agents x 16 obstacle rows (8 ellipse + 8 collision cone) per GPU, "
                                    "DBM filter, alpha=1, R=diag(.5,.5), ring of %d distinct batches" % (A, RING),
                        "agents_per_gpu": A, "rows": M, "lanes_per_qp": args.lanes,
+                       "obs_layout": "planes (M,2,A,4)" if args.planes else "tiles (A/64,M,2,64,4)",
                        "launch": "eager" if graph is None else "hipGraph of %d launches" % RING},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,

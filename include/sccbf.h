@@ -68,6 +68,10 @@ extern "C" {
 /* flags */
 #define SCCBF_FLAG_OBS_SHARED 1u     /* obs is T[M][2][4], one table for all agents */
 #define SCCBF_FLAG_TYPE_PER_AGENT 2u /* obs_type is u8[M][A] */
+#define SCCBF_FLAG_OBS_TILED 8u     /* obs is T[ceil(A/64)][M][2][64][4]: tiles of 64 agents, each
+                                        tile one contiguous 128 M-vector block (best HBM locality when
+                                        several lanes cooperate on a QP); the last tile may be partly
+                                        unused but must be allocated */
 #define SCCBF_FLAG_SLIP_IO 4u        /* u_ref[1] / u_out[1] are already in QP coordinates (slip
                                         angle beta for DBM, yaw rate omega for KBM): skip the
                                         steering transforms of reference cbf/cbf.py:175,216,75,109 */

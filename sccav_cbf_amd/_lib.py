@@ -10,8 +10,9 @@ from ._build import LIB
 OBS_ELLIPSE, OBS_CONE, OBS_LANE, OBS_RADIAL, OBS_EMPTY = 0, 1, 2, 3, 255
 DYN_DBM, DYN_KBM = 0, 1
 STATUS_OPTIMAL, STATUS_INFEASIBLE, STATUS_NONFINITE = 0, 1, 2
-FLAG_OBS_SHARED, FLAG_TYPE_PER_AGENT, FLAG_SLIP_IO = 1, 2, 4
+FLAG_OBS_SHARED, FLAG_TYPE_PER_AGENT, FLAG_SLIP_IO, FLAG_OBS_TILED = 1, 2, 4, 8
 MAX_ROWS = 1024
+ERR_ARG, ERR_ROWS, ERR_WEIGHT, ERR_LAUNCH, ERR_VARIANT, ERR_NO_DEVICE = -1, -2, -3, -4, -5, -6
 
 EXPORTS = ("sccbf_version", "sccbf_strerror", "sccbf_default_params", "sccbf_solve_f32",
            "sccbf_solve_f64", "sccbf_qp_f32", "sccbf_qp_f64", "sccbf_partials_f32",

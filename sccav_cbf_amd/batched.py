@@ -11,7 +11,8 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import (DYN_DBM, DYN_KBM, FLAG_OBS_SHARED, FLAG_SLIP_IO, FLAG_TYPE_PER_AGENT, OBS_CONE, OBS_ELLIPSE,
+from ._lib import (DYN_DBM, DYN_KBM, FLAG_OBS_SHARED, FLAG_OBS_TILED, FLAG_SLIP_IO, FLAG_TYPE_PER_AGENT,
+                   OBS_CONE, OBS_ELLIPSE,
                    OBS_EMPTY, OBS_LANE, OBS_RADIAL)
 
 _DYN = {"dbm": DYN_DBM, "kbm": DYN_KBM, DYN_DBM: DYN_DBM, DYN_KBM: DYN_KBM}
@@ -67,8 +68,9 @@ class BatchedCBF:
     # -- the hot path
     def solve(self, state, u_ref, obs, obs_type, u_out=None, status=None, rows_out=None,
               want_rows=False):
-        """state (A,4), u_ref (A,2), obs (M,2,A,4) [or (M,2,4): one table shared by all
-        agents], obs_type uint8 (M,) [or (M,A)].  Returns (u_out (A,2), status (A,) int32)
+        """state (A,4), u_ref (A,2), obs (M,2,A,4) [or (ceil(A/64),M,2,64,4): tiles of 64 agents,
+        see pack_obs_tiled; or (M,2,4): one table shared by all agents], obs_type uint8 (M,)
+        [or (M,A)].  Returns (u_out (A,2), status (A,) int32)
         and, with want_rows/rows_out, rows (M,A,4) = Lg_h0, Lg_h1, b, h.
         Asynchronous on the current stream."""
         if not state.is_cuda:
@@ -77,10 +79,13 @@ class BatchedCBF:
         if dt not in (torch.float32, torch.float64):
             raise TypeError("state must be float32 or float64")
         A = state.shape[0]
-        M = obs.shape[0]
+        M = obs.shape[1] if obs.dim() == 5 else obs.shape[0]
         dev = state.device
         flags = FLAG_SLIP_IO if self.slip_io else 0
-        if obs.dim() == 3:
+        if obs.dim() == 5:
+            flags |= FLAG_OBS_TILED
+            exp_obs = ((A + 63) // 64, M, 2, 64, 4)
+        elif obs.dim() == 3:
             flags |= FLAG_OBS_SHARED
             exp_obs = (M, 2, 4)
         else:
@@ -169,6 +174,25 @@ def _stack8(*cols):
         return torch.tensor([float(c) for c in cols], dtype=torch.float64)
     out = [c if torch.is_tensor(c) else torch.full_like(ref, float(c)) for c in cols]
     return torch.stack(out, dim=-1)
+
+
+def pack_obs_tiled(slots):
+    """(M, A, 8) per-agent slots -> tiled ABI layout (ceil(A/64), M, 2, 64, 4); the unused
+    lanes of a last partial tile are zero."""
+    M, A, _ = slots.shape
+    T = (A + 63) // 64
+    out = slots.new_zeros((T * 64, M, 2, 4))
+    out[:A] = slots.reshape(M, A, 2, 4).permute(1, 0, 2, 3)
+    return out.reshape(T, 64, M, 2, 4).permute(0, 2, 3, 1, 4).contiguous()
+
+
+def planes_to_tiled(obs):
+    """(M, 2, A, 4) -> (ceil(A/64), M, 2, 64, 4)."""
+    M, _, A, _ = obs.shape
+    T = (A + 63) // 64
+    out = obs.new_zeros((M, 2, T * 64, 4))
+    out[:, :, :A] = obs
+    return out.reshape(M, 2, T, 64, 4).permute(2, 0, 1, 3, 4).contiguous()
 
 
 def pack_obs(slots):

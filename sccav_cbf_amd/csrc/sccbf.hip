@@ -378,6 +378,25 @@ template <typename T> struct Ego {
     T un0, un1;  // nominal input in QP coordinates
 };
 
+// Where the two 4-vectors of slot m of agent a live, in units of 4-vectors:
+//   planes (default)  obs[m][h][a]            index = a + m * 2A + h * A
+//   tiled             obs[a/64][m][h][a%64]   index = (a/64) * 128 M + a%64 + m * 128 + h * 64
+//   shared            obs[m][h]               index = m * 2 + h
+struct ObsAddr {
+    long long base, slot, half;
+    __device__ long long at(int m) const { return base + (long long)m * slot; }
+};
+template <typename T> __device__ inline ObsAddr obs_addr_(const KArgs<T>& p, long long a)
+{
+    ObsAddr r;
+    const bool shared = (p.flags & SCCBF_FLAG_OBS_SHARED) != 0;
+    const bool tiled = (p.flags & SCCBF_FLAG_OBS_TILED) != 0;
+    r.base = shared ? 0 : (tiled ? (a >> 6) * (long long)(128 * p.M) + (a & 63) : a);
+    r.slot = shared ? 2 : (tiled ? 128 : 2 * p.A);
+    r.half = shared ? 1 : (tiled ? 64 : p.A);
+    return r;
+}
+
 // One obstacle slot -> constraint row  a . u >= b  (u-space) and barrier value h.
 // DBM contraction: reference cbf/cbf.py:159-164, 200-207.  KBM: cbf/cbf.py:94-101.
 template <typename T>
@@ -507,7 +526,6 @@ __global__ __launch_bounds__(kBlock) void k_group(const KArgs<T> p)
 
     using v2 = typename VT<T>::v2;
     const int M = p.M;
-    const bool shared = !QP_ONLY && (p.flags & SCCBF_FLAG_OBS_SHARED) != 0;
     const bool type_pa = (p.flags & SCCBF_FLAG_TYPE_PER_AGENT) != 0;
     const v4* obs4 = reinterpret_cast<const v4*>(p.obs);
 
@@ -517,8 +535,7 @@ __global__ __launch_bounds__(kBlock) void k_group(const KArgs<T> p)
     const v2 urv = reinterpret_cast<const v2*>(p.u_ref)[qp];
     v4 sv = v4{T(0), T(0), T(0), T(0)};
     if (!QP_ONLY) sv = reinterpret_cast<const v4*>(p.state)[qp];
-    const long long plane = shared ? 1 : p.A;       // distance between the 4-vectors of a slot
-    const long long aoff = shared ? 0 : qp;
+    const ObsAddr oad = obs_addr_(p, qp);
     const long long tstr = type_pa ? p.A : 1, toff = type_pa ? qp : 0;
     v4 oa[RPL], ob[RPL];
     int ty[RPL];
@@ -534,10 +551,10 @@ __global__ __launch_bounds__(kBlock) void k_group(const KArgs<T> p)
             oa[r] = obs4[(long long)mm * p.A + qp];
             ob[r] = v4{T(0), T(0), T(0), T(0)};
         } else {
-            const long long i0 = (long long)mm * 2 * plane + aoff;
+            const long long i0 = oad.at(mm);
             ty[r] = p.obs_type[(long long)mm * tstr + toff];
             oa[r] = obs4[i0];
-            ob[r] = obs4[i0 + plane];
+            ob[r] = obs4[i0 + oad.half];
         }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -631,9 +648,9 @@ __global__ __launch_bounds__(WPB * 64) void k_wave(const KArgs<T> p)
     const bool live = qp < p.A;
     if (!live) qp = p.A - 1;  // keep the wave for the block barrier; its stores are masked
 
-    const bool shared = (p.flags & SCCBF_FLAG_OBS_SHARED) != 0;
     const bool type_pa = (p.flags & SCCBF_FLAG_TYPE_PER_AGENT) != 0;
     const v4* obs4 = reinterpret_cast<const v4*>(p.obs);
+    const ObsAddr oad = obs_addr_(p, qp);
 
     Ego<T> e;
     T ur0, ur1;
@@ -646,9 +663,9 @@ __global__ __launch_bounds__(WPB * 64) void k_wave(const KArgs<T> p)
             const v4 rw = obs4[(long long)m * p.A + qp];
             a0 = rw.x; a1 = rw.y; b = rw.z; h = T(0);
         } else {
-            const long long i0 = shared ? (long long)m * 2 : (long long)m * 2 * p.A + qp;
+            const long long i0 = oad.at(m);
             const v4 oa = obs4[i0];
-            const v4 ob = obs4[i0 + (shared ? 1 : p.A)];
+            const v4 ob = obs4[i0 + oad.half];
             const int ty = type_pa ? p.obs_type[(long long)m * p.A + qp] : p.obs_type[m];
             const T o[8] = {oa.x, oa.y, oa.z, oa.w, ob.x, ob.y, ob.z, ob.w};
             slot_row_(ty, o, e, p, a0, a1, b, h);
@@ -703,12 +720,12 @@ __global__ __launch_bounds__(kBlock) void k_partials(const KArgs<T> p)
     if (gid >= p.A * p.M) return;
     const int m = (int)(gid / p.A);
     const long long a = gid % p.A;
-    const bool shared = (p.flags & SCCBF_FLAG_OBS_SHARED) != 0;
     const bool type_pa = (p.flags & SCCBF_FLAG_TYPE_PER_AGENT) != 0;
     const v4* obs4 = reinterpret_cast<const v4*>(p.obs);
-    const long long i0 = shared ? (long long)m * 2 : (long long)m * 2 * p.A + a;
+    const ObsAddr oad = obs_addr_(p, a);
+    const long long i0 = oad.at(m);
     const v4 oa = obs4[i0];
-    const v4 ob = obs4[i0 + (shared ? 1 : p.A)];
+    const v4 ob = obs4[i0 + oad.half];
     const int ty = type_pa ? p.obs_type[(long long)m * p.A + a] : p.obs_type[m];
     const v4 s = reinterpret_cast<const v4*>(p.state)[a];
     T sth, cth;
@@ -752,6 +769,7 @@ int fill_args(const sccbf_params* sp, int64_t A, int32_t M, KArgs<T>& k)
     if (!sp || A < 0 || M < 0) return SCCBF_ERR_ARG;
     if (M > SCCBF_MAX_ROWS) return SCCBF_ERR_ROWS;
     if (sp->dynamics != SCCBF_DYN_DBM && sp->dynamics != SCCBF_DYN_KBM) return SCCBF_ERR_ARG;
+    if ((sp->flags & SCCBF_FLAG_OBS_SHARED) && (sp->flags & SCCBF_FLAG_OBS_TILED)) return SCCBF_ERR_ARG;
     const double r00 = sp->R[0], r01 = 0.5 * (sp->R[1] + sp->R[2]), r11 = sp->R[3];
     if (!(r00 > 0.0) || !std::isfinite(r00) || !std::isfinite(r01) || !std::isfinite(r11))
         return SCCBF_ERR_WEIGHT;

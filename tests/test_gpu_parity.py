@@ -255,6 +255,51 @@ def test_shared_obstacle_table(oracle):
         assert (sg == so).all() and np.abs(ug - uo).max() <= 1e-8 * (1 + np.abs(uo).max())
 
 
+@pytest.mark.parametrize("lanes", ALL_LANES)
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
+def test_tiled_obstacle_layout(oracle, lanes, dtype):
+    """obs as tiles of 64 agents, (ceil(A/64), M, 2, 64, 4): the bits of the planes layout for
+    every kernel variant, batch sizes with a partial last tile included, and the oracle's answer."""
+    from sccav_cbf_amd.batched import pack_obs, pack_obs_tiled, planes_to_tiled
+    for A, M in ((1, 3), (63, 16), (64, 8), (65, 16), (1000, 16), (4097, 5), (130, 33)):
+        if lanes not in (0, 64) and M > 16 * lanes:
+            continue
+        w = scenarios.monte_carlo(A, (M + 1) // 2, M // 2, 4242 + A, nominal="uniform")
+        t = _to_dev(w, dtype)
+        tiles = planes_to_tiled(t["obs"])
+        assert tiles.shape == ((A + 63) // 64, M, 2, 64, 4)
+        slots = t["obs"].permute(0, 2, 1, 3).reshape(M, A, 8)
+        assert torch.equal(pack_obs(slots), t["obs"]) and torch.equal(pack_obs_tiled(slots), tiles)
+        f = _filter(lanes=lanes, slip_io=True)
+        up, sp, rp = f.solve(t["state"], t["u_ref"], t["obs"], t["obs_type"], want_rows=True)
+        ut, st, rt = f.solve(t["state"], t["u_ref"], tiles, t["obs_type"], want_rows=True)
+        assert torch.equal(up, ut) and torch.equal(sp, st) and torch.equal(rp, rt)
+        if dtype == torch.float64:
+            uo, so, ro = _orc_solve(oracle, w)
+            assert (st.cpu().numpy() == so).all()
+            assert np.abs(ut.cpu().numpy() - uo).max() <= 1e-8 * (1 + np.abs(uo).max())
+    # the partials entry point reads the same layout
+    lib = _lib.load()
+    w = scenarios.monte_carlo(130, 3, 2, 5, nominal="uniform")
+    t = _to_dev(w, dtype)
+    outs = []
+    for obs, fl in ((t["obs"], 0), (planes_to_tiled(t["obs"]), _lib.FLAG_OBS_TILED)):
+        out = torch.empty((5, 2, 130, 4), dtype=dtype, device=_dev())
+        p = _lib.Params()
+        lib.sccbf_default_params(C.byref(p))
+        p.flags = fl
+        fn = lib.sccbf_partials_f64 if dtype == torch.float64 else lib.sccbf_partials_f32
+        _lib.check(fn(C.byref(p), 130, 5, t["state"].data_ptr(), obs.data_ptr(), t["obs_type"].data_ptr(),
+                      out.data_ptr(), None))
+        torch.cuda.synchronize()
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1])
+    # one table for all agents has no tiled form
+    p.flags = _lib.FLAG_OBS_TILED | _lib.FLAG_OBS_SHARED
+    assert fn(C.byref(p), 130, 5, t["state"].data_ptr(), obs.data_ptr(), t["obs_type"].data_ptr(),
+              out.data_ptr(), None) == _lib.ERR_ARG
+
+
 def test_nonfinite_inputs_are_flagged(oracle):
     w = scenarios.config4(A=300, nominal="uniform")
     w["state"][5, 0] = np.nan

@@ -143,6 +143,7 @@ int main(int argc, char** argv)
 {
     const long long A = argc > 1 ? atoll(argv[1]) : 65536;
     const int M = 16, RING = argc > 2 ? atoi(argv[2]) : 10, ITERS = 400;
+    const bool tiled = argc > 3 && atoi(argv[3]) != 0;  // upload obs as [A/64][M][2][64][4]
     std::mt19937 rng(1);
     std::uniform_real_distribution<float> U(-1.f, 1.f);
     std::vector<Batch> ring(RING);
@@ -163,6 +164,16 @@ int main(int argc, char** argv)
                 if (m < 8) { o0[2] = 11 + 9 * U(rng); o0[3] = 5.5f + 4.5f * U(rng); o1[0] = 3.14f * U(rng); o1[1] = 2 * U(rng); o1[2] = 2 * U(rng); o1[3] = 0; }
                 else { o0[2] = 3.14f * U(rng); o0[3] = 2.5f + 2.5f * U(rng); o1[0] = 4.5f + 2 * U(rng); o1[1] = 0; o1[2] = 0; o1[3] = 0; }
             }
+        if (tiled) {
+            std::vector<float> hz(ho.size());
+            for (int m = 0; m < M; ++m)
+                for (int h = 0; h < 2; ++h)
+                    for (long long a = 0; a < A; ++a)
+                        for (int c = 0; c < 4; ++c)
+                            hz[((((size_t)(a >> 6) * M + m) * 2 + h) * 64 + (a & 63)) * 4 + c] =
+                                ho[(((size_t)m * 2 + h) * A + a) * 4 + c];
+            ho.swap(hz);
+        }
         Batch& B = ring[b];
         CK(hipMalloc(&B.state, A * 16)); CK(hipMalloc(&B.u_ref, A * 8)); CK(hipMalloc(&B.obs, (size_t)M * 2 * A * 16));
         CK(hipMalloc(&B.u_out, A * 8)); CK(hipMalloc(&B.status, A * 4)); CK(hipMalloc(&B.type, M));
@@ -175,6 +186,7 @@ int main(int argc, char** argv)
     sccbf_default_params(&sp);
     sp.R[0] = sp.R[3] = 0.5;
     KArgs<float> k;
+    if (tiled) sp.flags |= SCCBF_FLAG_OBS_TILED;
     fill_args<float>(&sp, A, M, k);
     const double bytes = (double)A * (4.0 * (4 + 2 + 8 * M + 2) + 4);
     auto report = [&](const char* name, float us) {
@@ -185,6 +197,7 @@ int main(int argc, char** argv)
         k.state = ring[b].state; k.u_ref = ring[b].u_ref; k.obs = ring[b].obs; k.obs_type = ring[b].type;
         k.u_out = ring[b].u_out; k.status = ring[b].status; k.rows_out = nullptr;
     };
+    printf("layout %s  ", tiled ? "tiled" : "planes");
     printf("A=%lld M=%d ring=%d  algorithmic bytes/launch %.0f\n", A, M, RING, bytes);
     for (int blocks : {256, 512, 1024, 2048, 4096}) {
         char nm[64];
