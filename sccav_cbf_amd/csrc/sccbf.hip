@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <cmath>
+#include <type_traits>
 
 #include "sccbf.h"
 
@@ -167,6 +168,16 @@ template <int G, typename Op> __device__ inline unsigned group_reduce(unsigned v
 }
 template <int G> __device__ inline unsigned group_umax(unsigned v) { return group_reduce<G>(v, OpMax()); }
 template <int G> __device__ inline unsigned group_or(unsigned v) { return group_reduce<G>(v, OpOr()); }
+struct OpIMax { __device__ unsigned operator()(unsigned a, unsigned b) const { return (int)a > (int)b ? a : b; } };
+template <int G> __device__ inline int group_imax(int v) { return (int)group_reduce<G>((unsigned)v, OpIMax()); }
+// value that is non-zero in at most one lane of the group -> all lanes
+template <int G> __device__ inline float group_bcast(float v) { return __uint_as_float(group_or<G>(__float_as_uint(v))); }
+template <int G> __device__ inline double group_bcast(double v)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = group_or<G>((unsigned)b), hi = group_or<G>((unsigned)(b >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
 // value held by exactly one lane of the group (the others pass `mine = false`) -> all lanes
 template <int G> __device__ inline float group_pick(float v, bool mine)
 {
@@ -178,9 +189,22 @@ template <int G> __device__ inline double group_pick(double v, bool mine)
     const unsigned lo = group_or<G>((unsigned)b), hi = group_or<G>((unsigned)(b >> 32));
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
-// order-preserving 32-bit image of a positive violation (fp64 is narrowed first)
-__device__ inline unsigned viol_bits(float v) { return __float_as_uint(v); }
-__device__ inline unsigned viol_bits(double v) { return __float_as_uint(fmaxf((float)v, 1.17549435e-38f)); }
+// 32-bit image of a violation whose order as a signed integer is the order of the
+// violations that exceed thr; everything at or below thr maps below every one of those.
+// fp32: the bits themselves (negative floats are negative integers; the comparison with
+// thr happens once, on the group's maximum).  fp64: compared here at full precision, then
+// narrowed (clamped into the normal fp32 range so the image stays positive and ordered).
+__device__ inline unsigned viol_bits(float v, float) { return __float_as_uint(v); }
+__device__ inline unsigned viol_bits(double v, double thr)
+{
+    return v > thr ? __float_as_uint(fminf(fmaxf((float)v, 1.17549435e-38f), 3.0e38f)) : 0x80000000u;
+}
+// order-preserving image of a violation already known to be positive
+__device__ inline unsigned viol_bits_pos(float v) { return __float_as_uint(v); }
+__device__ inline unsigned viol_bits_pos(double v) { return __float_as_uint(fmaxf((float)v, 1.17549435e-38f)); }
+// does the winning key stand for a violation above thr?
+__device__ inline bool viol_key_above(int key, float thr) { return __uint_as_float((unsigned)key & ~0xFFu) > thr; }
+__device__ inline bool viol_key_above(int key, double) { return key > 0xFF; }
 
 // ------------------------------------------------------------------- the 2-D QP
 // State of the active-set iteration, identical in every lane of a cooperative group:
@@ -197,13 +221,15 @@ template <typename T> struct Pivot {
 // bound t and the point nearest to the origin inside the bounds is taken.  The row that
 // clamps t (if any) stays active, the other one is released.  Straight-line code: every
 // lane evaluates it and `go` selects which lanes commit the result.
-template <typename T> __device__ inline void pivot_onto_(Pivot<T>& s, T c0, T c1, T cb, bool go)
+// NS_MAX: a bound on s.ns the caller knows at compile time (the first step of every QP has
+// no active row, the second at most one), which removes the arithmetic of the unused slots.
+template <int NS_MAX = 2, typename T> __device__ inline void pivot_onto_(Pivot<T>& s, T c0, T c1, T cb, bool go)
 {
     constexpr T kInf = INFINITY;
     const bool zero_row = (c0 == T(0)) & (c1 == T(0));  // 0 . u >= positive
     const T p0 = c0 * cb, p1 = c1 * cb;
     const T d0 = -c1, d1 = c0;
-    const bool v0 = s.ns > 0, v1 = s.ns > 1;
+    const bool v0 = NS_MAX > 0 && s.ns > 0, v1 = NS_MAX > 1 && s.ns > 1;
     const T cs0 = s.sa0[0] * d0 + s.sa1[0] * d1, cs1 = s.sa0[1] * d0 + s.sa1[1] * d1;
     const T ee0 = s.sb[0] - (s.sa0[0] * p0 + s.sa1[0] * p1);
     const T ee1 = s.sb[1] - (s.sa0[1] * p0 + s.sa1[1] * p1);
@@ -515,53 +541,62 @@ __device__ inline void store_result_(const KArgs<T>& p, long long qp, bool qp_on
 }
 
 // ------------------------------------------------- G lanes per QP, rows in registers
+// What one lane holds of one QP between its loads and its arithmetic.
+template <typename T, int RPL> struct LaneLoads {
+    typename VT<T>::v2 urv;
+    typename VT<T>::v4 sv;
+    typename VT<T>::v4 oa[RPL], ob[RPL];
+    int ty[RPL];
+};
+
+// Every load of lane g of QP `qp` is issued up front, in the order the arithmetic
+// consumes them (ego first, then slot by slot), as straight-line code: slots past M
+// re-read slot M-1 and are turned into empty rows afterwards.
 template <typename T, int G, int RPL, bool QP_ONLY>
-__global__ __launch_bounds__(kBlock) void k_group(const KArgs<T> p)
+__device__ inline void group_load_(const KArgs<T>& p, long long qp, int g, LaneLoads<T, RPL>& L)
 {
     using v4 = typename VT<T>::v4;
-    const long long gid = (long long)blockIdx.x * kBlock + threadIdx.x;
-    const long long qp = gid / G;
-    const int g = (int)(gid % G);
-    if (qp >= p.A) return;  // groups are lane-aligned: a whole group leaves together
-
     using v2 = typename VT<T>::v2;
     const int M = p.M;
     const bool type_pa = (p.flags & SCCBF_FLAG_TYPE_PER_AGENT) != 0;
     const v4* obs4 = reinterpret_cast<const v4*>(p.obs);
-
-    // Every load of this lane is issued up front, in the order the arithmetic consumes
-    // them (ego first, then slot by slot), as straight-line code: slots past M re-read
-    // slot M-1 and are turned into empty rows afterwards.
-    const v2 urv = reinterpret_cast<const v2*>(p.u_ref)[qp];
-    v4 sv = v4{T(0), T(0), T(0), T(0)};
-    if (!QP_ONLY) sv = reinterpret_cast<const v4*>(p.state)[qp];
+    L.urv = reinterpret_cast<const v2*>(p.u_ref)[qp];
+    L.sv = v4{T(0), T(0), T(0), T(0)};
+    if (!QP_ONLY) L.sv = reinterpret_cast<const v4*>(p.state)[qp];
     const ObsAddr oad = obs_addr_(p, qp);
     const long long tstr = type_pa ? p.A : 1, toff = type_pa ? qp : 0;
-    v4 oa[RPL], ob[RPL];
-    int ty[RPL];
 #pragma unroll
     for (int r = 0; r < RPL; ++r) {
         const int m = r * G + g;
         const int mm = m < M ? m : M - 1;
-        ty[r] = 0;
+        L.ty[r] = 0;
         // keep the issue order (the vmcnt counter retires loads in order, so the order
         // decides how early each row's arithmetic may start)
         __builtin_amdgcn_sched_barrier(0);
         if (QP_ONLY) {  // the host never launches this kernel with M = 0
-            oa[r] = obs4[(long long)mm * p.A + qp];
-            ob[r] = v4{T(0), T(0), T(0), T(0)};
+            L.oa[r] = obs4[(long long)mm * p.A + qp];
+            L.ob[r] = v4{T(0), T(0), T(0), T(0)};
         } else {
             const long long i0 = oad.at(mm);
-            ty[r] = p.obs_type[(long long)mm * tstr + toff];
-            oa[r] = obs4[i0];
-            ob[r] = obs4[i0 + oad.half];
+            L.ty[r] = p.obs_type[(long long)mm * tstr + toff];
+            L.oa[r] = obs4[i0];
+            L.ob[r] = obs4[i0 + oad.half];
         }
     }
     __builtin_amdgcn_sched_barrier(0);
+}
+
+// Rows of this lane from its loaded slots, then the active-set iteration of the group.
+template <typename T, int G, int RPL, bool QP_ONLY>
+__device__ inline void group_solve_(const KArgs<T>& p, long long qp, int g, bool live,
+                                    const LaneLoads<T, RPL>& L)
+{
+    using v4 = typename VT<T>::v4;
+    const int M = p.M;
     Ego<T> e;
     T ur0, ur1;
     int bad;
-    make_ego_(p, sv, urv, QP_ONLY, e, ur0, ur1, bad);
+    make_ego_(p, L.sv, L.urv, QP_ONLY, e, ur0, ur1, bad);
 
     // rows of this lane, unit normals in w-space
     T at0[RPL], at1[RPL], bt[RPL];
@@ -571,12 +606,13 @@ __global__ __launch_bounds__(kBlock) void k_group(const KArgs<T> p)
         const int m = r * G + g;
         T a0, a1, b, h;
         if (QP_ONLY) {
-            a0 = oa[r].x; a1 = oa[r].y; b = oa[r].z; h = T(0);
+            a0 = L.oa[r].x; a1 = L.oa[r].y; b = L.oa[r].z; h = T(0);
             if (m >= M) { a0 = T(0); a1 = T(0); b = T(-1); }
         } else {
-            const T o[8] = {oa[r].x, oa[r].y, oa[r].z, oa[r].w, ob[r].x, ob[r].y, ob[r].z, ob[r].w};
-            slot_row_(m < M ? ty[r] : SCCBF_OBS_EMPTY, o, e, p, a0, a1, b, h);
-            if (p.rows_out && m < M)
+            const T o[8] = {L.oa[r].x, L.oa[r].y, L.oa[r].z, L.oa[r].w,
+                            L.ob[r].x, L.ob[r].y, L.ob[r].z, L.ob[r].w};
+            slot_row_(m < M ? L.ty[r] : SCCBF_OBS_EMPTY, o, e, p, a0, a1, b, h);
+            if (p.rows_out && m < M && live)
                 reinterpret_cast<v4*>(p.rows_out)[(long long)m * p.A + qp] = v4{a0, a1, b, h};
         }
         chk += a0 * T(0) + a1 * T(0) + b * T(0);
@@ -594,41 +630,85 @@ __global__ __launch_bounds__(kBlock) void k_group(const KArgs<T> p)
 #pragma unroll
     for (int r = 0; r < RPL; ++r) idx[r] = (unsigned)(255 - (r * G + g));
     const int cap = 8 * M + 32;
-    for (int it = 0;; ++it) {  // wave-uniform trip count, lanes commit under `go`
-        // rows are unit-normal, so bt - a.w is a distance; below this it is rounding
+    // One step: find the most violated row of the group, move the optimum onto it.
+    // Returns false (wave-uniform) once no group of the wave has work left.
+    auto step = [&](auto ns_max, bool first, int it) -> bool {
+        // rows are unit-normal, so bt - a.w is a distance; below thr it is rounding
         const T thr = Lim<T>::viol_tol * (abs_(s.w0) + abs_(s.w1)) + Lim<T>::tiny_n2;
-        unsigned kbest = 0u;
+        // key = violation in the high bits, idx below: the maximum is the most violated
+        // row and the keys of a group are distinct.  Keys are compared as signed integers,
+        // so a row that is satisfied (negative violation) loses against any violated one.
+        int key[RPL];
+        int kbest = (int)0x80000000;
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) {
+            const T viol = first ? bt[r] : bt[r] - at0[r] * s.w0 - at1[r] * s.w1;
+            key[r] = (int)((viol_bits(viol, thr) & ~0xFFu) | idx[r]);
+            kbest = key[r] > kbest ? key[r] : kbest;
+        }
+        const int kmax = group_imax<G>(kbest);
+        const bool go = (s.st == SCCBF_STATUS_OPTIMAL) & viol_key_above(kmax, thr);
+        if (!__any(go)) return false;  // every group of the wave is done
+        if (it >= cap) {               // no convergence: rows numerically inconsistent
+            s.st = go ? SCCBF_STATUS_INFEASIBLE : s.st;
+            return false;
+        }
+        // the lane that holds the winning row publishes it (the other lanes contribute 0)
         T c0 = T(0), c1 = T(0), cb = T(0);
 #pragma unroll
         for (int r = 0; r < RPL; ++r) {
-            const T viol = bt[r] - (at0[r] * s.w0 + at1[r] * s.w1);
-            // violation in the high bits, idx below: the max is the most violated row and
-            // every key of a group is distinct
-            const unsigned key = viol > thr ? ((viol_bits(viol) & ~0xFFu) | idx[r]) : 0u;
-            const bool better = key > kbest;
-            kbest = better ? key : kbest;
-            c0 = better ? at0[r] : c0;
-            c1 = better ? at1[r] : c1;
-            cb = better ? bt[r] : cb;
-        }
-        const unsigned kmax = group_umax<G>(kbest);
-        const bool go = (s.st == SCCBF_STATUS_OPTIMAL) & (kmax != 0u);
-        if (!__any(go)) break;  // every group of the wave is done
-        if (it >= cap) {        // no convergence: rows numerically inconsistent
-            s.st = go ? SCCBF_STATUS_INFEASIBLE : s.st;
-            break;
+            const bool sel = key[r] == kmax;
+            c0 = sel ? at0[r] : c0;
+            c1 = sel ? at1[r] : c1;
+            cb = sel ? bt[r] : cb;
         }
         if (G > 1) {
-            const bool mine = kbest == kmax;
-            c0 = group_pick<G>(c0, mine);
-            c1 = group_pick<G>(c1, mine);
-            cb = group_pick<G>(cb, mine);
+            c0 = group_bcast<G>(c0);
+            c1 = group_bcast<G>(c1);
+            cb = group_bcast<G>(cb);
         }
-        pivot_onto_(s, c0, c1, cb, go);
+        pivot_onto_<decltype(ns_max)::value>(s, c0, c1, cb, go);
+        return true;
+    };
+    // wave-uniform trip count, lanes commit under `go`; the first step starts from w = 0
+    // with no active row and the second one has at most one
+    if (step(std::integral_constant<int, 0>(), true, 0) && step(std::integral_constant<int, 1>(), false, 1)) {
+        for (int it = 2; step(std::integral_constant<int, 2>(), false, it); ++it) {}
     }
     const int st = s.st;
     const T w0 = s.w0, w1 = s.w1;
-    if (g == 0) store_result_(p, qp, QP_ONLY, st, w0, w1, e, ur0, ur1);
+    if (g == 0 && live) store_result_(p, qp, QP_ONLY, st, w0, w1, e, ur0, ur1);
+}
+
+// Each group of G lanes solves S QPs one after the other; the loads of all S are in
+// flight from the start, so the arithmetic of one QP runs while the data of the next
+// ones still stream in (a batch too small to give every SIMD several rounds of waves has
+// no other overlap between its memory phase and its solve phase).
+template <typename T, int G, int RPL, bool QP_ONLY, int S>
+__global__ __launch_bounds__(kBlock) void k_group(const KArgs<T> p)
+{
+    constexpr int kQps = kBlock / G;  // QPs per workgroup and set
+    const int g = (int)(threadIdx.x % G);
+    if (S == 1) {
+        const long long qp = (long long)blockIdx.x * kQps + threadIdx.x / G;
+        if (qp >= p.A) return;  // groups are lane-aligned: a whole group leaves together
+        LaneLoads<T, RPL> L;
+        group_load_<T, G, RPL, QP_ONLY>(p, qp, g, L);
+        group_solve_<T, G, RPL, QP_ONLY>(p, qp, g, true, L);
+        return;
+    }
+    LaneLoads<T, RPL> L[S];
+    long long qp[S];
+    bool live[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        qp[s] = ((long long)blockIdx.x * S + s) * kQps + threadIdx.x / G;
+        live[s] = qp[s] < p.A;
+        if (!live[s]) qp[s] = p.A - 1;  // loads stay in bounds, stores are masked
+        group_load_<T, G, RPL, QP_ONLY>(p, qp[s], g, L[s]);
+    }
+#pragma unroll
+    for (int s = 0; s < S; ++s) group_solve_<T, G, RPL, QP_ONLY>(p, qp[s], g, live[s], L[s]);
 }
 
 // ------------------------------------------ one wavefront per QP, rows staged in LDS
@@ -692,7 +772,7 @@ __global__ __launch_bounds__(WPB * 64) void k_wave(const KArgs<T> p)
         unsigned kbest = 0u;
         for (int m = lane; m < M; m += 64) {
             const T viol = s_bt[m] - (s_at0[m] * s.w0 + s_at1[m] * s.w1);
-            const unsigned key = viol > thr ? ((viol_bits(viol) & ~0x3FFu) | (unsigned)(1023 - m)) : 0u;
+            const unsigned key = viol > thr ? ((viol_bits_pos(viol) & ~0x3FFu) | (unsigned)(1023 - m)) : 0u;
             kbest = key > kbest ? key : kbest;
         }
         const unsigned kmax = group_umax<64>(kbest);
@@ -805,13 +885,13 @@ int auto_lanes(int64_t A, int M)
     return g;
 }
 
-template <typename T, bool QP_ONLY, int G, int RPL>
+template <typename T, bool QP_ONLY, int G, int RPL, int S = 1>
 int launch_group(const KArgs<T>& k, hipStream_t s)
 {
-    const long long threads = k.A * G;
-    const long long blocks = (threads + kBlock - 1) / kBlock;
+    const long long per_block = (long long)S * (kBlock / G);
+    const long long blocks = (k.A + per_block - 1) / per_block;
     if (blocks > 0x7fffffffLL) return SCCBF_ERR_ARG;
-    hipLaunchKernelGGL((k_group<T, G, RPL, QP_ONLY>), dim3((unsigned)blocks), dim3(kBlock), 0, s, k);
+    hipLaunchKernelGGL((k_group<T, G, RPL, QP_ONLY, S>), dim3((unsigned)blocks), dim3(kBlock), 0, s, k);
     return hipGetLastError() == hipSuccess ? SCCBF_OK : SCCBF_ERR_LAUNCH;
 }
 
