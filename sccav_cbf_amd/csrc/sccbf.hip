@@ -32,6 +32,10 @@ namespace {
 #define SCCBF_BLOCK 256  // threads per workgroup of the group / passthrough / partials kernels
 #endif
 constexpr int kBlock = SCCBF_BLOCK;
+#ifndef SCCBF_TILE
+#define SCCBF_TILE 64  // agents per tile of the tiled obstacle layout
+#endif
+constexpr int kTile = SCCBF_TILE;
 constexpr int kLaneIters = 32;     // Newton iterations for the lane closest point
 constexpr int kLaneHalvings = 30;  // step halvings per iteration
 
@@ -64,16 +68,14 @@ template <typename T> struct KArgs {
 };
 
 // ------------------------------------------------------------------ math shims
-// fp32: the hardware sin/cos unit (argument in revolutions) after a two-term reduction
-// by 2 pi; 1-ulp rcp / sqrt / rsq instead of the IEEE division and denormal-safe sqrt
+// fp32: the hardware sin/cos unit (argument in revolutions, reduced to [0, 1) so that any
+// magnitude is in its range; the angle error is |x| 2^-24, 2e-7 rad for a heading in
+// [-pi, pi]); 1-ulp rcp / sqrt / rsq instead of the IEEE division and denormal-safe sqrt
 // sequences.  Library sincosf/tanf would pull a Payne-Hanek reduction with a scratch
 // table into every call site.  fp64 keeps the full-accuracy library forms.
 __device__ inline void sincos_(float x, float* s, float* c)
 {
-    const float k = rintf(x * 0.15915494309189535f);
-    float y = fmaf(-k, 6.2831854820251465f, x);
-    y = fmaf(-k, -1.7484555314695172e-7f, y);
-    const float r = y * 0.15915494309189535f;
+    const float r = __builtin_amdgcn_fractf(x * 0.15915494309189535f);
     *s = __builtin_amdgcn_sinf(r);
     *c = __builtin_amdgcn_cosf(r);
 }
@@ -208,60 +210,82 @@ __device__ inline bool viol_key_above(int key, double) { return key > 0xFF; }
 
 // ------------------------------------------------------------------- the 2-D QP
 // State of the active-set iteration, identical in every lane of a cooperative group:
-// the current optimum w and the (at most two) rows that are active at it.
+// the current optimum w and two stored rows: the rows active at w, or rows that were
+// active earlier and are satisfied at w (keeping a satisfied row of the problem among the
+// stored ones changes no optimum), or the null row 0 . w >= -1 of an unused slot.
 template <typename T> struct Pivot {
     T w0, w1;
     T sa0[2], sa1[2], sb[2];
-    int ns;
     int st;
+    __device__ void reset(int status)
+    {
+        w0 = w1 = T(0);
+        sa0[0] = sa0[1] = sa1[0] = sa1[1] = T(0);
+        sb[0] = sb[1] = T(-1);
+        st = status;
+    }
 };
 
 // Move the optimum onto the violated row c . w = cb (unit normal c): the new optimum of
-// {active rows} + {this row} lies on that line; along it, w = p + t d, the active rows
+// {stored rows} + {this row} lies on that line; along it, w = p + t d, the stored rows
 // bound t and the point nearest to the origin inside the bounds is taken.  The row that
-// clamps t (if any) stays active, the other one is released.  Straight-line code: every
-// lane evaluates it and `go` selects which lanes commit the result.
-// NS_MAX: a bound on s.ns the caller knows at compile time (the first step of every QP has
-// no active row, the second at most one), which removes the arithmetic of the unused slots.
-template <int NS_MAX = 2, typename T> __device__ inline void pivot_onto_(Pivot<T>& s, T c0, T c1, T cb, bool go)
+// clamps t (if any) is kept with the new one.  Straight-line code: every lane evaluates it
+// and `go` selects which lanes commit the result.
+// NS: how many stored slots can hold a real row, known at compile time (the first step of
+// every QP has none, the second at most one); the arithmetic of the other slots vanishes.
+template <int NS = 2, typename T> __device__ inline void pivot_onto_(Pivot<T>& s, T c0, T c1, T cb, bool go)
 {
     constexpr T kInf = INFINITY;
     const bool zero_row = (c0 == T(0)) & (c1 == T(0));  // 0 . u >= positive
     const T p0 = c0 * cb, p1 = c1 * cb;
     const T d0 = -c1, d1 = c0;
-    const bool v0 = NS_MAX > 0 && s.ns > 0, v1 = NS_MAX > 1 && s.ns > 1;
-    const T cs0 = s.sa0[0] * d0 + s.sa1[0] * d1, cs1 = s.sa0[1] * d0 + s.sa1[1] * d1;
-    const T ee0 = s.sb[0] - (s.sa0[0] * p0 + s.sa1[0] * p1);
-    const T ee1 = s.sb[1] - (s.sa0[1] * p0 + s.sa1[1] * p1);
-    const bool np0 = abs_(cs0) > Lim<T>::par_tol, np1 = abs_(cs1) > Lim<T>::par_tol;
-    const T t0 = div_(ee0, cs0), t1 = div_(ee1, cs1);  // garbage for parallel / unused slots
-    const bool lo0 = v0 & np0 & (cs0 > T(0)), lo1 = v1 & np1 & (cs1 > T(0));
-    const bool hi0 = v0 & np0 & !(cs0 > T(0)), hi1 = v1 & np1 & !(cs1 > T(0));
-    const T tl0 = lo0 ? t0 : -kInf, tl1 = lo1 ? t1 : -kInf;
-    const T th0 = hi0 ? t0 : kInf, th1 = hi1 ? t1 : kInf;
-    const bool l1 = tl1 > tl0, h1 = th1 < th0;
-    const T tlo = l1 ? tl1 : tl0, thi = h1 ? th1 : th0;
-    // parallel rows facing each other with a gap, or crossing bounds: no common point
-    bool inf = (v0 & !np0 & (ee0 > Lim<T>::feas_tol * (abs_(s.sb[0]) + abs_(cb)) + Lim<T>::tiny_n2)) |
-               (v1 & !np1 & (ee1 > Lim<T>::feas_tol * (abs_(s.sb[1]) + abs_(cb)) + Lim<T>::tiny_n2));
-    inf |= tlo > thi + Lim<T>::feas_tol * (abs_(tlo) + abs_(thi));
+    T tlo = -kInf, thi = kInf;
+    bool l1 = false, h1 = false, inf = false;
+    if (NS > 0) {
+        const T cs0 = s.sa1[0] * d1 + s.sa0[0] * d0;
+        const T ee0 = s.sb[0] - s.sa0[0] * p0 - s.sa1[0] * p1;
+        const bool np0 = abs_(cs0) > Lim<T>::par_tol;  // a null row is "parallel" and never binds
+        const T t0 = div_(ee0, cs0);                   // garbage for parallel rows
+        const bool up0 = cs0 > T(0);
+        tlo = (np0 & up0) ? t0 : -kInf;
+        thi = (np0 & !up0) ? t0 : kInf;
+        // parallel rows facing each other with a gap: no common point
+        inf = !np0 & (ee0 > Lim<T>::feas_tol * (abs_(s.sb[0]) + abs_(cb)) + Lim<T>::tiny_n2);
+    }
+    if (NS > 1) {
+        const T cs1 = s.sa1[1] * d1 + s.sa0[1] * d0;
+        const T ee1 = s.sb[1] - s.sa0[1] * p0 - s.sa1[1] * p1;
+        const bool np1 = abs_(cs1) > Lim<T>::par_tol;
+        const T t1 = div_(ee1, cs1);
+        const bool up1 = cs1 > T(0);
+        const T tl1 = (np1 & up1) ? t1 : -kInf;
+        const T th1 = (np1 & !up1) ? t1 : kInf;
+        l1 = tl1 > tlo;
+        h1 = th1 < thi;
+        tlo = l1 ? tl1 : tlo;
+        thi = h1 ? th1 : thi;
+        inf |= !np1 & (ee1 > Lim<T>::feas_tol * (abs_(s.sb[1]) + abs_(cb)) + Lim<T>::tiny_n2);
+        // bounds that cross: three rows without a common point
+        inf |= tlo > thi + Lim<T>::feas_tol * (abs_(tlo) + abs_(thi));
+    }
     const bool bad = zero_row | inf;
     const bool uselo = tlo > T(0);
     const bool usehi = !uselo & (thi < T(0));
     const T t = uselo ? tlo : (usehi ? thi : T(0));
-    const bool keepany = uselo | usehi;
-    const bool keep1 = uselo ? l1 : h1;  // the clamping row sits in slot 1 (else slot 0)
+    // the clamping row must end up in slot 1; it sits there already when keep1
+    const bool keep1 = (uselo & l1) | (usehi & h1);
     const bool upd = go & !bad;
-    const bool mv = upd & keepany & !keep1;
+    const bool mv = upd & !keep1;  // slot 0 (clamping, or merely satisfied) moves to slot 1
     s.w0 = upd ? p0 + t * d0 : s.w0;
     s.w1 = upd ? p1 + t * d1 : s.w1;
-    s.sa0[1] = mv ? s.sa0[0] : s.sa0[1];
-    s.sa1[1] = mv ? s.sa1[0] : s.sa1[1];
-    s.sb[1] = mv ? s.sb[0] : s.sb[1];
+    if (NS > 0) {
+        s.sa0[1] = mv ? s.sa0[0] : s.sa0[1];
+        s.sa1[1] = mv ? s.sa1[0] : s.sa1[1];
+        s.sb[1] = mv ? s.sb[0] : s.sb[1];
+    }
     s.sa0[0] = upd ? c0 : s.sa0[0];
     s.sa1[0] = upd ? c1 : s.sa1[0];
     s.sb[0] = upd ? cb : s.sb[0];
-    s.ns = upd ? (keepany ? 2 : 1) : s.ns;
     s.st = (go & bad) ? SCCBF_STATUS_INFEASIBLE : s.st;
 }
 
@@ -408,18 +432,21 @@ template <typename T> struct Ego {
 //   planes (default)  obs[m][h][a]            index = a + m * 2A + h * A
 //   tiled             obs[a/64][m][h][a%64]   index = (a/64) * 128 M + a%64 + m * 128 + h * 64
 //   shared            obs[m][h]               index = m * 2 + h
+// The strides are 32-bit (2 A < 2^32) so that base + m * slot is one 64-bit multiply-add.
 struct ObsAddr {
-    long long base, slot, half;
-    __device__ long long at(int m) const { return base + (long long)m * slot; }
+    unsigned long long base;
+    unsigned slot, half;
+    __device__ unsigned long long at(int m) const { return base + (unsigned long long)(unsigned)m * slot; }
 };
 template <typename T> __device__ inline ObsAddr obs_addr_(const KArgs<T>& p, long long a)
 {
     ObsAddr r;
     const bool shared = (p.flags & SCCBF_FLAG_OBS_SHARED) != 0;
     const bool tiled = (p.flags & SCCBF_FLAG_OBS_TILED) != 0;
-    r.base = shared ? 0 : (tiled ? (a >> 6) * (long long)(128 * p.M) + (a & 63) : a);
-    r.slot = shared ? 2 : (tiled ? 128 : 2 * p.A);
-    r.half = shared ? 1 : (tiled ? 64 : p.A);
+    r.base = shared ? 0ull : (tiled ? (unsigned long long)(a / kTile) * (unsigned)(2 * kTile * p.M) + (unsigned)(a % kTile)
+                                    : (unsigned long long)a);
+    r.slot = shared ? 2u : (tiled ? 2u * kTile : 2u * (unsigned)p.A);
+    r.half = shared ? 1u : (tiled ? (unsigned)kTile : (unsigned)p.A);
     return r;
 }
 
@@ -564,7 +591,8 @@ __device__ inline void group_load_(const KArgs<T>& p, long long qp, int g, LaneL
     L.sv = v4{T(0), T(0), T(0), T(0)};
     if (!QP_ONLY) L.sv = reinterpret_cast<const v4*>(p.state)[qp];
     const ObsAddr oad = obs_addr_(p, qp);
-    const long long tstr = type_pa ? p.A : 1, toff = type_pa ? qp : 0;
+    const unsigned tstr = type_pa ? (unsigned)p.A : 1u;
+    const unsigned long long toff = type_pa ? (unsigned long long)qp : 0ull;
 #pragma unroll
     for (int r = 0; r < RPL; ++r) {
         const int m = r * G + g;
@@ -577,8 +605,8 @@ __device__ inline void group_load_(const KArgs<T>& p, long long qp, int g, LaneL
             L.oa[r] = obs4[(long long)mm * p.A + qp];
             L.ob[r] = v4{T(0), T(0), T(0), T(0)};
         } else {
-            const long long i0 = oad.at(mm);
-            L.ty[r] = p.obs_type[(long long)mm * tstr + toff];
+            const unsigned long long i0 = oad.at(mm);
+            L.ty[r] = p.obs_type[(unsigned long long)(unsigned)mm * tstr + toff];
             L.oa[r] = obs4[i0];
             L.ob[r] = obs4[i0 + oad.half];
         }
@@ -588,8 +616,7 @@ __device__ inline void group_load_(const KArgs<T>& p, long long qp, int g, LaneL
 
 // Rows of this lane from its loaded slots, then the active-set iteration of the group.
 template <typename T, int G, int RPL, bool QP_ONLY>
-__device__ inline void group_solve_(const KArgs<T>& p, long long qp, int g, bool live,
-                                    const LaneLoads<T, RPL>& L)
+__device__ inline void group_solve_(const KArgs<T>& p, long long qp, int g, const LaneLoads<T, RPL>& L)
 {
     using v4 = typename VT<T>::v4;
     const int M = p.M;
@@ -612,7 +639,7 @@ __device__ inline void group_solve_(const KArgs<T>& p, long long qp, int g, bool
             const T o[8] = {L.oa[r].x, L.oa[r].y, L.oa[r].z, L.oa[r].w,
                             L.ob[r].x, L.ob[r].y, L.ob[r].z, L.ob[r].w};
             slot_row_(m < M ? L.ty[r] : SCCBF_OBS_EMPTY, o, e, p, a0, a1, b, h);
-            if (p.rows_out && m < M && live)
+            if (p.rows_out && m < M)
                 reinterpret_cast<v4*>(p.rows_out)[(long long)m * p.A + qp] = v4{a0, a1, b, h};
         }
         chk += a0 * T(0) + a1 * T(0) + b * T(0);
@@ -621,11 +648,28 @@ __device__ inline void group_solve_(const KArgs<T>& p, long long qp, int g, bool
     bad |= !(chk == T(0));
     bad = (int)group_or<G>((unsigned)bad);
 
+    // The rows also go to LDS, row m of the group's QP at [component][qp slot][m], so that
+    // the winning row of a step is one indexed read per component instead of a chain of
+    // selects over the registers of every lane.  Each wavefront reads only what it wrote.
+    constexpr int kMpad = G * RPL + 1;          // odd stride between QPs: fewer bank conflicts
+    constexpr int kPlane = (kBlock / G) * kMpad;
+    constexpr bool kLdsPick = (size_t)3 * kPlane * sizeof(T) <= 53 * 1024;  // 3 workgroups per CU at most
+    __shared__ T s_rows[kLdsPick ? 3 * kPlane : 1];
+    const int qslot = (int)(threadIdx.x / G) * kMpad;
+    if (kLdsPick) {
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) {
+            s_rows[qslot + r * G + g] = at0[r];
+            s_rows[kPlane + qslot + r * G + g] = at1[r];
+            s_rows[2 * kPlane + qslot + r * G + g] = bt[r];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+
     // active-set iteration: take the most violated row, move the optimum onto it
     Pivot<T> s;
-    s.w0 = T(0); s.w1 = T(0); s.ns = 0;
-    s.sa0[0] = s.sa0[1] = s.sa1[0] = s.sa1[1] = s.sb[0] = s.sb[1] = T(0);
-    s.st = bad ? SCCBF_STATUS_NONFINITE : SCCBF_STATUS_OPTIMAL;
+    s.reset(bad ? SCCBF_STATUS_NONFINITE : SCCBF_STATUS_OPTIMAL);
     unsigned idx[RPL];  // 255 - row index: ties in violation go to the lowest index
 #pragma unroll
     for (int r = 0; r < RPL; ++r) idx[r] = (unsigned)(255 - (r * G + g));
@@ -639,12 +683,12 @@ __device__ inline void group_solve_(const KArgs<T>& p, long long qp, int g, bool
         // row and the keys of a group are distinct.  Keys are compared as signed integers,
         // so a row that is satisfied (negative violation) loses against any violated one.
         int key[RPL];
-        int kbest = (int)0x80000000;
+        int kbest = 0;
 #pragma unroll
         for (int r = 0; r < RPL; ++r) {
             const T viol = first ? bt[r] : bt[r] - at0[r] * s.w0 - at1[r] * s.w1;
             key[r] = (int)((viol_bits(viol, thr) & ~0xFFu) | idx[r]);
-            kbest = key[r] > kbest ? key[r] : kbest;
+            kbest = (r == 0 || key[r] > kbest) ? key[r] : kbest;  // always the key of a real slot
         }
         const int kmax = group_imax<G>(kbest);
         const bool go = (s.st == SCCBF_STATUS_OPTIMAL) & viol_key_above(kmax, thr);
@@ -653,19 +697,26 @@ __device__ inline void group_solve_(const KArgs<T>& p, long long qp, int g, bool
             s.st = go ? SCCBF_STATUS_INFEASIBLE : s.st;
             return false;
         }
-        // the lane that holds the winning row publishes it (the other lanes contribute 0)
         T c0 = T(0), c1 = T(0), cb = T(0);
+        if (kLdsPick) {
+            const int at = qslot + 255 - (kmax & 0xFF);
+            c0 = s_rows[at];
+            c1 = s_rows[kPlane + at];
+            cb = s_rows[2 * kPlane + at];
+        } else {
+            // the lane that holds the winning row publishes it (the other lanes contribute 0)
 #pragma unroll
-        for (int r = 0; r < RPL; ++r) {
-            const bool sel = key[r] == kmax;
-            c0 = sel ? at0[r] : c0;
-            c1 = sel ? at1[r] : c1;
-            cb = sel ? bt[r] : cb;
-        }
-        if (G > 1) {
-            c0 = group_bcast<G>(c0);
-            c1 = group_bcast<G>(c1);
-            cb = group_bcast<G>(cb);
+            for (int r = 0; r < RPL; ++r) {
+                const bool sel = key[r] == kmax;
+                c0 = sel ? at0[r] : c0;
+                c1 = sel ? at1[r] : c1;
+                cb = sel ? bt[r] : cb;
+            }
+            if (G > 1) {
+                c0 = group_bcast<G>(c0);
+                c1 = group_bcast<G>(c1);
+                cb = group_bcast<G>(cb);
+            }
         }
         pivot_onto_<decltype(ns_max)::value>(s, c0, c1, cb, go);
         return true;
@@ -677,38 +728,18 @@ __device__ inline void group_solve_(const KArgs<T>& p, long long qp, int g, bool
     }
     const int st = s.st;
     const T w0 = s.w0, w1 = s.w1;
-    if (g == 0 && live) store_result_(p, qp, QP_ONLY, st, w0, w1, e, ur0, ur1);
+    if (g == 0) store_result_(p, qp, QP_ONLY, st, w0, w1, e, ur0, ur1);
 }
 
-// Each group of G lanes solves S QPs one after the other; the loads of all S are in
-// flight from the start, so the arithmetic of one QP runs while the data of the next
-// ones still stream in (a batch too small to give every SIMD several rounds of waves has
-// no other overlap between its memory phase and its solve phase).
-template <typename T, int G, int RPL, bool QP_ONLY, int S>
+template <typename T, int G, int RPL, bool QP_ONLY>
 __global__ __launch_bounds__(kBlock) void k_group(const KArgs<T> p)
 {
-    constexpr int kQps = kBlock / G;  // QPs per workgroup and set
     const int g = (int)(threadIdx.x % G);
-    if (S == 1) {
-        const long long qp = (long long)blockIdx.x * kQps + threadIdx.x / G;
-        if (qp >= p.A) return;  // groups are lane-aligned: a whole group leaves together
-        LaneLoads<T, RPL> L;
-        group_load_<T, G, RPL, QP_ONLY>(p, qp, g, L);
-        group_solve_<T, G, RPL, QP_ONLY>(p, qp, g, true, L);
-        return;
-    }
-    LaneLoads<T, RPL> L[S];
-    long long qp[S];
-    bool live[S];
-#pragma unroll
-    for (int s = 0; s < S; ++s) {
-        qp[s] = ((long long)blockIdx.x * S + s) * kQps + threadIdx.x / G;
-        live[s] = qp[s] < p.A;
-        if (!live[s]) qp[s] = p.A - 1;  // loads stay in bounds, stores are masked
-        group_load_<T, G, RPL, QP_ONLY>(p, qp[s], g, L[s]);
-    }
-#pragma unroll
-    for (int s = 0; s < S; ++s) group_solve_<T, G, RPL, QP_ONLY>(p, qp[s], g, live[s], L[s]);
+    const long long qp = (long long)blockIdx.x * (kBlock / G) + threadIdx.x / G;
+    if (qp >= p.A) return;  // groups are lane-aligned: a whole group leaves together
+    LaneLoads<T, RPL> L;
+    group_load_<T, G, RPL, QP_ONLY>(p, qp, g, L);
+    group_solve_<T, G, RPL, QP_ONLY>(p, qp, g, L);
 }
 
 // ------------------------------------------ one wavefront per QP, rows staged in LDS
@@ -763,9 +794,7 @@ __global__ __launch_bounds__(WPB * 64) void k_wave(const KArgs<T> p)
     __syncthreads();
 
     Pivot<T> s;
-    s.w0 = T(0); s.w1 = T(0); s.ns = 0;
-    s.sa0[0] = s.sa0[1] = s.sa1[0] = s.sa1[1] = s.sb[0] = s.sb[1] = T(0);
-    s.st = bad ? SCCBF_STATUS_NONFINITE : SCCBF_STATUS_OPTIMAL;
+    s.reset(bad ? SCCBF_STATUS_NONFINITE : SCCBF_STATUS_OPTIMAL);
     const int cap = 8 * M + 32;
     for (int it = 0;; ++it) {  // wave-uniform loop
         const T thr = Lim<T>::viol_tol * (abs_(s.w0) + abs_(s.w1)) + Lim<T>::tiny_n2;
@@ -847,6 +876,7 @@ template <typename T>
 int fill_args(const sccbf_params* sp, int64_t A, int32_t M, KArgs<T>& k)
 {
     if (!sp || A < 0 || M < 0) return SCCBF_ERR_ARG;
+    if (A > 0x7fffffffLL) return SCCBF_ERR_ARG;  // the kernels keep strides of up to 2 A in 32 bits
     if (M > SCCBF_MAX_ROWS) return SCCBF_ERR_ROWS;
     if (sp->dynamics != SCCBF_DYN_DBM && sp->dynamics != SCCBF_DYN_KBM) return SCCBF_ERR_ARG;
     if ((sp->flags & SCCBF_FLAG_OBS_SHARED) && (sp->flags & SCCBF_FLAG_OBS_TILED)) return SCCBF_ERR_ARG;
@@ -885,13 +915,13 @@ int auto_lanes(int64_t A, int M)
     return g;
 }
 
-template <typename T, bool QP_ONLY, int G, int RPL, int S = 1>
+template <typename T, bool QP_ONLY, int G, int RPL>
 int launch_group(const KArgs<T>& k, hipStream_t s)
 {
-    const long long per_block = (long long)S * (kBlock / G);
+    const long long per_block = kBlock / G;
     const long long blocks = (k.A + per_block - 1) / per_block;
     if (blocks > 0x7fffffffLL) return SCCBF_ERR_ARG;
-    hipLaunchKernelGGL((k_group<T, G, RPL, QP_ONLY, S>), dim3((unsigned)blocks), dim3(kBlock), 0, s, k);
+    hipLaunchKernelGGL((k_group<T, G, RPL, QP_ONLY>), dim3((unsigned)blocks), dim3(kBlock), 0, s, k);
     return hipGetLastError() == hipSuccess ? SCCBF_OK : SCCBF_ERR_LAUNCH;
 }
 

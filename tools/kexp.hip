@@ -170,7 +170,7 @@ int main(int argc, char** argv)
                 for (int h = 0; h < 2; ++h)
                     for (long long a = 0; a < A; ++a)
                         for (int c = 0; c < 4; ++c)
-                            hz[((((size_t)(a >> 6) * M + m) * 2 + h) * 64 + (a & 63)) * 4 + c] =
+                            hz[((((size_t)(a / SCCBF_TILE) * M + m) * 2 + h) * SCCBF_TILE + (a % SCCBF_TILE)) * 4 + c] =
                                 ho[(((size_t)m * 2 + h) * A + a) * 4 + c];
             ho.swap(hz);
         }
@@ -217,9 +217,9 @@ int main(int argc, char** argv)
     report("loadonly G=" #G " 1 store/wave", time_it([&](int b) { setk(b); hipLaunchKernelGGL((k_loadonly<G, RPL, 3>), dim3((unsigned)((A * G + 255) / 256)), dim3(256), 0, 0, k); }, ITERS, RING)); \
     report("loadonly G=" #G " no ego, 1 store", time_it([&](int b) { setk(b); hipLaunchKernelGGL((k_loadonly<G, RPL, 4>), dim3((unsigned)((A * G + 255) / 256)), dim3(256), 0, 0, k); }, ITERS, RING)); \
     report("rowsonly G=" #G, time_it([&](int b) { setk(b); hipLaunchKernelGGL((k_rowsonly<G, RPL>), dim3((unsigned)((A * G + 255) / 256)), dim3(256), 0, 0, k); }, ITERS, RING)); \
-    report("full     G=" #G, time_it([&](int b) { setk(b); hipLaunchKernelGGL((k_group<float, G, RPL, false, 1>), dim3((unsigned)((A * G + kBlock - 1) / kBlock)), dim3(kBlock), 0, 0, k); }, ITERS, RING)); \
-    report("full S=2 G=" #G, time_it([&](int b) { setk(b); launch_group<float, false, G, RPL, 2>(k, 0); }, ITERS, RING)); \
-    report("full S=4 G=" #G, time_it([&](int b) { setk(b); launch_group<float, false, G, RPL, 4>(k, 0); }, ITERS, RING));
+    report("full     G=" #G, time_it([&](int b) { setk(b); hipLaunchKernelGGL((k_group<float, G, RPL, false>), dim3((unsigned)((A * G + kBlock - 1) / kBlock)), dim3(kBlock), 0, 0, k); }, ITERS, RING));
+#define RUN_OCC(G, RPL, LDS) \
+    report("full G=" #G " +lds " #LDS, time_it([&](int b) { setk(b); hipLaunchKernelGGL((k_group<float, G, RPL, false>), dim3((unsigned)((A * G + kBlock - 1) / kBlock)), dim3(kBlock), LDS, 0, k); }, ITERS, RING));
     RUN_G(1, 16)
     RUN_G(2, 8)
     RUN_G(4, 4)
