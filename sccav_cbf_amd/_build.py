@@ -14,6 +14,8 @@ HIPCC_FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
     # packed-fp32 forms have produced sporadic wrong results on this hardware pool
     "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops",
+    # leading scalar kernel arguments arrive in SGPRs at wave launch instead of through s_load
+    "-mllvm", "-amdgpu-kernarg-preload-count=16",
 ]
 
 

@@ -731,9 +731,16 @@ __device__ inline void group_solve_(const KArgs<T>& p, long long qp, int g, cons
     if (g == 0) store_result_(p, qp, QP_ONLY, st, w0, w1, e, ur0, ur1);
 }
 
+// The arguments every wave needs before it can issue its first loads come first and one
+// by one: the leading 16 dwords of the kernel arguments are preloaded into SGPRs at wave
+// launch (-amdgpu-kernarg-preload-count), which a by-value struct does not qualify for.
 template <typename T, int G, int RPL, bool QP_ONLY>
-__global__ __launch_bounds__(kBlock) void k_group(const KArgs<T> p)
+__global__ __launch_bounds__(kBlock) void k_group(long long A, const T* obs, const T* state, const T* u_ref,
+                                                  const uint8_t* obs_type, int M, unsigned flags,
+                                                  const KArgs<T> rest)
 {
+    KArgs<T> p = rest;
+    p.A = A; p.obs = obs; p.state = state; p.u_ref = u_ref; p.obs_type = obs_type; p.M = M; p.flags = flags;
     const int g = (int)(threadIdx.x % G);
     const long long qp = (long long)blockIdx.x * (kBlock / G) + threadIdx.x / G;
     if (qp >= p.A) return;  // groups are lane-aligned: a whole group leaves together
@@ -921,7 +928,8 @@ int launch_group(const KArgs<T>& k, hipStream_t s)
     const long long per_block = kBlock / G;
     const long long blocks = (k.A + per_block - 1) / per_block;
     if (blocks > 0x7fffffffLL) return SCCBF_ERR_ARG;
-    hipLaunchKernelGGL((k_group<T, G, RPL, QP_ONLY>), dim3((unsigned)blocks), dim3(kBlock), 0, s, k);
+    hipLaunchKernelGGL((k_group<T, G, RPL, QP_ONLY>), dim3((unsigned)blocks), dim3(kBlock), 0, s, k.A, k.obs,
+                       k.state, k.u_ref, k.obs_type, k.M, k.flags, k);
     return hipGetLastError() == hipSuccess ? SCCBF_OK : SCCBF_ERR_LAUNCH;
 }
 

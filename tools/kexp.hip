@@ -217,9 +217,7 @@ int main(int argc, char** argv)
     report("loadonly G=" #G " 1 store/wave", time_it([&](int b) { setk(b); hipLaunchKernelGGL((k_loadonly<G, RPL, 3>), dim3((unsigned)((A * G + 255) / 256)), dim3(256), 0, 0, k); }, ITERS, RING)); \
     report("loadonly G=" #G " no ego, 1 store", time_it([&](int b) { setk(b); hipLaunchKernelGGL((k_loadonly<G, RPL, 4>), dim3((unsigned)((A * G + 255) / 256)), dim3(256), 0, 0, k); }, ITERS, RING)); \
     report("rowsonly G=" #G, time_it([&](int b) { setk(b); hipLaunchKernelGGL((k_rowsonly<G, RPL>), dim3((unsigned)((A * G + 255) / 256)), dim3(256), 0, 0, k); }, ITERS, RING)); \
-    report("full     G=" #G, time_it([&](int b) { setk(b); hipLaunchKernelGGL((k_group<float, G, RPL, false>), dim3((unsigned)((A * G + kBlock - 1) / kBlock)), dim3(kBlock), 0, 0, k); }, ITERS, RING));
-#define RUN_OCC(G, RPL, LDS) \
-    report("full G=" #G " +lds " #LDS, time_it([&](int b) { setk(b); hipLaunchKernelGGL((k_group<float, G, RPL, false>), dim3((unsigned)((A * G + kBlock - 1) / kBlock)), dim3(kBlock), LDS, 0, k); }, ITERS, RING));
+    report("full     G=" #G, time_it([&](int b) { setk(b); launch_group<float, false, G, RPL>(k, 0); }, ITERS, RING));
     RUN_G(1, 16)
     RUN_G(2, 8)
     RUN_G(4, 4)
