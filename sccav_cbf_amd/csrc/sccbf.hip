@@ -6,7 +6,8 @@
 // Two kernel families share the row and QP arithmetic:
 //   k_group<T, G, RPL>  G cooperating lanes per QP (G = 1, 2, 4, 8, 16), each lane
 //                       keeps RPL rows in registers; cross-lane steps are DPP moves
-//                       inside the G-lane group.  G = 1 is one thread per QP.
+//                       inside the G-lane group, the winning row of a step comes back
+//                       from an LDS copy of the rows by index.  G = 1 is one thread per QP.
 //   k_wave<T, WPB>      one 64-lane wavefront per QP, rows staged in LDS, any M;
 //                       the most violated row is found by a wave-wide max.
 //
@@ -14,11 +15,12 @@
 // exactly: in w = Lc^T (u - u_nom), R = Lc Lc^T, it is the least-norm point of the
 // polygon { at_i . w >= bt_i }.  An active-set iteration starts at w = 0 with no
 // active row; while some row is violated, the most violated one is taken: the optimum
-// of {active rows} + {that row} lies on its line, so the 1-D problem along the line,
-// bounded by the (at most two) active rows, is solved, and the rows tight at the new
-// point become the active set.  |w| grows strictly with every step, so no active set
-// repeats; the loop ends with no violated row (optimal) or an empty 1-D interval
-// (three rows without a common point: infeasible).
+// of {stored rows} + {that row} lies on its line, so the 1-D problem along the line,
+// bounded by the two stored rows, is solved; the new row and the row that clamps the
+// 1-D optimum (else a row that is merely satisfied there) are stored for the next step.
+// |w| grows strictly with every step, so no active set repeats; the loop ends with no
+// violated row (optimal) or an empty 1-D interval (three rows without a common point:
+// infeasible).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <cmath>
@@ -48,6 +50,13 @@ template <> struct VT<double> {
     using v4 = double4;
     using v2 = double2;
 };
+
+template <typename T> __device__ inline typename VT<T>::v4 nt_load4_(const typename VT<T>::v4* ptr)
+{
+    typedef T raw4 __attribute__((ext_vector_type(4)));
+    const raw4 r = __builtin_nontemporal_load(reinterpret_cast<const raw4*>(ptr));
+    return typename VT<T>::v4{r.x, r.y, r.z, r.w};
+}
 
 template <typename T> struct KArgs {
     T alpha, lr, lf, L, inv_lr, inv_L;
@@ -579,7 +588,9 @@ template <typename T, int RPL> struct LaneLoads {
 // Every load of lane g of QP `qp` is issued up front, in the order the arithmetic
 // consumes them (ego first, then slot by slot), as straight-line code: slots past M
 // re-read slot M-1 and are turned into empty rows afterwards.
-template <typename T, int G, int RPL, bool QP_ONLY>
+// NT: obstacle slots are loaded with the non-temporal hint (read once, not worth keeping in
+// L2 / Infinity Cache); pays off for batches much larger than those caches.
+template <typename T, int G, int RPL, bool QP_ONLY, bool NT>
 __device__ inline void group_load_(const KArgs<T>& p, long long qp, int g, LaneLoads<T, RPL>& L)
 {
     using v4 = typename VT<T>::v4;
@@ -607,8 +618,13 @@ __device__ inline void group_load_(const KArgs<T>& p, long long qp, int g, LaneL
         } else {
             const unsigned long long i0 = oad.at(mm);
             L.ty[r] = p.obs_type[(unsigned long long)(unsigned)mm * tstr + toff];
-            L.oa[r] = obs4[i0];
-            L.ob[r] = obs4[i0 + oad.half];
+            if (NT) {
+                L.oa[r] = nt_load4_<T>(&obs4[i0]);
+                L.ob[r] = nt_load4_<T>(&obs4[i0 + oad.half]);
+            } else {
+                L.oa[r] = obs4[i0];
+                L.ob[r] = obs4[i0 + oad.half];
+            }
         }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -734,7 +750,7 @@ __device__ inline void group_solve_(const KArgs<T>& p, long long qp, int g, cons
 // The arguments every wave needs before it can issue its first loads come first and one
 // by one: the leading 16 dwords of the kernel arguments are preloaded into SGPRs at wave
 // launch (-amdgpu-kernarg-preload-count), which a by-value struct does not qualify for.
-template <typename T, int G, int RPL, bool QP_ONLY>
+template <typename T, int G, int RPL, bool QP_ONLY, bool NT>
 __global__ __launch_bounds__(kBlock) void k_group(long long A, const T* obs, const T* state, const T* u_ref,
                                                   const uint8_t* obs_type, int M, unsigned flags,
                                                   const KArgs<T> rest)
@@ -745,7 +761,7 @@ __global__ __launch_bounds__(kBlock) void k_group(long long A, const T* obs, con
     const long long qp = (long long)blockIdx.x * (kBlock / G) + threadIdx.x / G;
     if (qp >= p.A) return;  // groups are lane-aligned: a whole group leaves together
     LaneLoads<T, RPL> L;
-    group_load_<T, G, RPL, QP_ONLY>(p, qp, g, L);
+    group_load_<T, G, RPL, QP_ONLY, NT>(p, qp, g, L);
     group_solve_<T, G, RPL, QP_ONLY>(p, qp, g, L);
 }
 
@@ -907,20 +923,24 @@ int fill_args(const sccbf_params* sp, int64_t A, int32_t M, KArgs<T>& k)
     return SCCBF_OK;
 }
 
-// lanes-per-QP when the caller leaves the choice to the library
+// lanes-per-QP when the caller leaves the choice to the library (measured on MI355X with
+// 16 rows: 4 lanes from 32768 QPs up to 1M, 8 around 8192-16384, 16 below; the
+// one-wavefront-per-QP kernel only when the rows do not fit 16 lanes x 16 registers)
 int auto_lanes(int64_t A, int M)
 {
-    if (M > 64) return 64;
     int g;
-    if (A >= (1 << 18)) g = 1;
-    else if (A >= (1 << 17)) g = 2;
-    else if (A >= (1 << 14)) g = 4;
-    else if (A >= 256) g = 16;
-    else return 64;
+    if (A >= (1 << 15)) g = 4;
+    else if (A >= (1 << 13)) g = 8;
+    else g = 16;
     while (g < 16 && M > 16 * g) g *= 2;  // keep at most 16 rows per lane
     if (M > 16 * g) return 64;
     return g;
 }
+
+// Obstacle bytes per launch from which the slots are loaded non-temporally: measured
+// break-even between 34 MB (cached loads 8% faster) and 67 MB (non-temporal 1-4% faster,
+// 5-10% from 134 MB on).
+constexpr double kNtBytes = 48.0 * 1024 * 1024;
 
 template <typename T, bool QP_ONLY, int G, int RPL>
 int launch_group(const KArgs<T>& k, hipStream_t s)
@@ -928,8 +948,14 @@ int launch_group(const KArgs<T>& k, hipStream_t s)
     const long long per_block = kBlock / G;
     const long long blocks = (k.A + per_block - 1) / per_block;
     if (blocks > 0x7fffffffLL) return SCCBF_ERR_ARG;
-    hipLaunchKernelGGL((k_group<T, G, RPL, QP_ONLY>), dim3((unsigned)blocks), dim3(kBlock), 0, s, k.A, k.obs,
-                       k.state, k.u_ref, k.obs_type, k.M, k.flags, k);
+    // rows of the QP-only entry are a third of the bytes of obstacle slots: always cached loads
+    const bool nt = !QP_ONLY && (double)k.A * k.M * 8 * sizeof(T) >= kNtBytes;
+    if (nt)
+        hipLaunchKernelGGL((k_group<T, G, RPL, QP_ONLY, !QP_ONLY>), dim3((unsigned)blocks), dim3(kBlock), 0, s, k.A,
+                           k.obs, k.state, k.u_ref, k.obs_type, k.M, k.flags, k);
+    else
+        hipLaunchKernelGGL((k_group<T, G, RPL, QP_ONLY, false>), dim3((unsigned)blocks), dim3(kBlock), 0, s, k.A,
+                           k.obs, k.state, k.u_ref, k.obs_type, k.M, k.flags, k);
     return hipGetLastError() == hipSuccess ? SCCBF_OK : SCCBF_ERR_LAUNCH;
 }
 

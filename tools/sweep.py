@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--dtype", default="f32")
     ap.add_argument("--rows", type=int, default=16)
     ap.add_argument("--reps", type=int, default=0)
+    ap.add_argument("--layouts", default="planes,tiles")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     dt = torch.float32 if args.dtype == "f32" else torch.float64
@@ -52,7 +53,7 @@ def main():
             ring.append(t)
         ty = torch.from_numpy(np.tile(base["obs_type"], -(-M // 16))[:M].copy()).to(dev)
         reps = args.reps or max(20, min(400, int(4e9 // (abytes * n))))
-        for layout in ("planes", "tiles"):
+        for layout in args.layouts.split(","):
             for L in [int(s) for s in args.lanes.split(",")]:
                 flt = BatchedCBF(alpha=1.0, lr=1.45, lf=1.45, R=np.diag([0.5, 0.5]), lanes_per_qp=L)
                 st = torch.cuda.Stream(dev)
