@@ -67,9 +67,39 @@ def cpu_baseline(seconds=10.0):
         orc.solve_batch(p, w["state"], w["u_ref"], w["obs"], w["obs_type"])
         n += 1
     dt = time.perf_counter() - t0
-    return {"value": n * AGENTS / dt, "unit": "solves/s", "cores": threads, "kind": "port",
-            "sample": "%d passes of the fp64 C oracle (OpenMP, %d threads) over one 65536-agent x 16-row "
-                      "batch, %.1f s" % (n, threads, dt)}
+    out = {"value": n * AGENTS / dt, "unit": "solves/s", "cores": threads, "kind": "port",
+           "sample": "%d passes of the fp64 C oracle (OpenMP, %d threads) over one 65536-agent x 16-row "
+                     "batch, %.1f s" % (n, threads, dt)}
+    # the reference hands every QP to an interpreted general-purpose solver (cvxopt.solvers.cp,
+    # cbf/cbf.py:213); cvxopt is not installed here, so scipy's SLSQP on the same rows stands in
+    try:
+        out["interpreted_solver_proxy"] = slsqp_proxy(orc, p, w)
+    except Exception as e:  # scipy missing or failing must not cost the bench line
+        out["interpreted_solver_proxy"] = {"error": repr(e)}
+    return out
+
+
+def slsqp_proxy(orc, p, w, n_qp=192, budget=6.0):
+    """One scipy SLSQP call per QP, rows from the oracle, single process."""
+    from scipy.optimize import minimize
+    idx = np.arange(n_qp)
+    p = orc.make_params(alpha=1.0, R=(0.5, 0, 0, 0.5), flags=orc.FLAG_SLIP_IO)  # rows and u_ref in QP coordinates
+    _, st, rows = orc.solve_batch(p, w["state"][idx], w["u_ref"][idx],
+                                  np.ascontiguousarray(w["obs"][:, :, idx, :]), w["obs_type"], want_rows=True)
+    R = np.diag([0.5, 0.5])
+    done, t0 = 0, time.perf_counter()
+    for a in idx:
+        un = w["u_ref"][a]
+        G, b = rows[:, a - idx[0], :2], rows[:, a - idx[0], 2]
+        minimize(lambda u: (u - un) @ R @ (u - un), un, jac=lambda u: 2 * R @ (u - un), method="SLSQP",
+                 constraints=[{"type": "ineq", "fun": lambda u: G @ u - b, "jac": lambda u: G}])
+        done += 1
+        if time.perf_counter() - t0 > budget:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": done / dt, "unit": "solves/s", "cores": 1,
+            "solver": "scipy.optimize.minimize(method='SLSQP') per QP on the oracle's rows (cvxopt absent)",
+            "sample": "%d QPs, %.1f s" % (done, dt)}
 
 
 def main():
@@ -149,6 +179,27 @@ def main():
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
     wall = float(tw.item())
 
+    # Outside the timed region: what collecting every rank's answers costs per step (the solve
+    # itself never communicates).  all_gather of u_out (A,2) f32 and status (A,) i32 over RCCL.
+    gather_ms = None
+    if dist is not None:
+        try:
+            gu = torch.empty((world * A, 2), dtype=torch.float32, device=device)
+            gs = torch.empty((world * A,), dtype=torch.int32, device=device)
+            reps = 20
+            for i in range(3 + reps):
+                if i == 3:
+                    torch.cuda.synchronize()
+                    tg = time.perf_counter()
+                dist.all_gather_into_tensor(gu, ring[0]["u_out"])
+                dist.all_gather_into_tensor(gs, ring[0]["status"])
+            torch.cuda.synchronize()
+            tg = torch.tensor([(time.perf_counter() - tg) / reps * 1e3], dtype=torch.float64, device=device)
+            dist.all_reduce(tg, op=dist.ReduceOp.MAX)
+            gather_ms = float(tg.item())
+        except Exception as e:  # never at the price of the bench line
+            print("gather timing skipped: %r" % (e,), file=sys.stderr)
+
     status = torch.stack([b["status"] for b in ring]).cpu().numpy()
     counts = np.bincount(status.reshape(-1), minlength=3)
 
@@ -183,6 +234,8 @@ def main():
             "status_counts": {"optimal": int(counts[0]), "infeasible": int(counts[1]),
                               "nonfinite": int(counts[2])},
         }
+        if gather_ms is not None:
+            out["gather_ms_per_step"] = gather_ms   # not part of value / ms_per_step
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -23,7 +23,10 @@
  *   obs      T[M][2][A][4]  obstacle slot m of agent a = the two 4-vectors
  *                           obs[m][0][a][:] and obs[m][1][a][:]  (8 scalars);
  *                           with SCCBF_FLAG_OBS_SHARED the table is T[M][2][4]
- *                           and is broadcast to every agent
+ *                           and is broadcast to every agent; with
+ *                           SCCBF_FLAG_OBS_TILED it is T[ceil(A/64)][M][2][64][4],
+ *                           agent a at tile a/64, position a%64 (the faster
+ *                           layout: one contiguous block per 64 agents)
  *   obs_type u8[M]          slot kind, shared by all agents; with
  *                           SCCBF_FLAG_TYPE_PER_AGENT it is u8[M][A]
  *   u_out    T[A][2]        DBM: a*, delta*             KBM: v*, delta*
@@ -68,17 +71,17 @@ extern "C" {
 /* flags */
 #define SCCBF_FLAG_OBS_SHARED 1u     /* obs is T[M][2][4], one table for all agents */
 #define SCCBF_FLAG_TYPE_PER_AGENT 2u /* obs_type is u8[M][A] */
-#define SCCBF_FLAG_OBS_TILED 8u     /* obs is T[ceil(A/64)][M][2][64][4]: tiles of 64 agents, each
-                                        tile one contiguous 128 M-vector block (best HBM locality when
-                                        several lanes cooperate on a QP); the last tile may be partly
-                                        unused but must be allocated */
 #define SCCBF_FLAG_SLIP_IO 4u        /* u_ref[1] / u_out[1] are already in QP coordinates (slip
                                         angle beta for DBM, yaw rate omega for KBM): skip the
                                         steering transforms of reference cbf/cbf.py:175,216,75,109 */
+#define SCCBF_FLAG_OBS_TILED 8u      /* obs is T[ceil(A/64)][M][2][64][4]: tiles of 64 agents, each
+                                        tile one contiguous block of 128 M 4-vectors; the last tile
+                                        may be partly unused but must be allocated in full; not
+                                        combinable with SCCBF_FLAG_OBS_SHARED */
 
 /* error codes */
 #define SCCBF_OK 0
-#define SCCBF_ERR_ARG (-1)         /* NULL pointer / negative size / bad enum */
+#define SCCBF_ERR_ARG (-1)         /* NULL pointer / negative size / A >= 2^31 / bad enum or flags */
 #define SCCBF_ERR_ROWS (-2)        /* M above SCCBF_MAX_ROWS */
 #define SCCBF_ERR_WEIGHT (-3)      /* R not symmetric positive definite */
 #define SCCBF_ERR_LAUNCH (-4)      /* hipLaunch failed */
