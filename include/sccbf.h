@@ -167,6 +167,61 @@ int sccbf_partials_f64(const sccbf_params* p, int64_t A, int32_t M,
                        const double* state, const double* obs, const uint8_t* obs_type,
                        double* out, void* stream);
 
+/*
+ * Nominal input in front of the filter, for A agents on one shared course.
+ * Steering: LateralStanley.control, reference cbf/controllers.py:69-151 (the same law
+ * is restated in test_scripts/stanley_controller_ellipse.py:146-212): nearest
+ * way-point to the front axle over the WHOLE course (first index on ties), target
+ * index never moving backwards, delta = normalize(yaw_des[idx] - yaw) +
+ * atan2(k e, v + ks) with e the cross-track error at the nearest way-point.
+ * Speed: PID1.control, cbf/controllers.py:173-180, on e = target_speed - v.
+ */
+typedef struct sccbf_nominal_params {
+    double axle;         /* reference point -> front axle [m]: lf in LateralStanley
+                            (controllers.py:80-81), the wheel base L in the driver scripts */
+    double k, ks;        /* Stanley gains (controllers.py:144) */
+    double kp, ki, kd;   /* PID1 gains */
+    double dt;           /* PID1 time step (controllers.py:163,170-171) */
+    double target_speed; /* [m/s] */
+    uint32_t flags;      /* SCCBF_NOMINAL_* */
+    int32_t reserved;
+} sccbf_nominal_params;
+
+#define SCCBF_NOMINAL_WAYPOINT_SPEED 1u /* track traj[idx][3] instead of target_speed */
+
+/* Defaults of the reference objects: k 0.5, ks 0.01 (controllers.py:36-37), kp 1,
+ * ki = kd = 0, dt 0.1 (155-163), axle 2.0 (lf, controllers.py:34), target 30 km/h
+ * (stanley_controller_ellipse.py:590). */
+void sccbf_default_nominal_params(sccbf_nominal_params* p);
+
+/*
+ *   state      T[A][4]   x, y, yaw, v
+ *   traj       T[N][4]   way-points x, y, yaw_des, v_des (N >= 1), shared by all agents
+ *   target_idx i32[A]    in: last target index (0 at the start); out: this tick's
+ *   pid_state  T[A][2]   in/out: previous error, error integral; NULL = proportional
+ *                        control only (a_ref = kp e)
+ *   u_ref      T[A][2]   out: a_ref, delta_ref  (what sccbf_solve_* takes as u_ref)
+ */
+int sccbf_nominal_f32(const sccbf_nominal_params* p, int64_t A, int32_t N,
+                      const float* state, const float* traj, int32_t* target_idx,
+                      float* pid_state, float* u_ref, void* stream);
+int sccbf_nominal_f64(const sccbf_nominal_params* p, int64_t A, int32_t N,
+                      const double* state, const double* traj, int32_t* target_idx,
+                      double* pid_state, double* u_ref, void* stream);
+
+/*
+ * Vehicle step of the closed-loop drivers: State.update_com, reference
+ * test_scripts/stanley_controller_ellipse.py:122-131.  delta is clipped to
+ * +-max_steer, beta = atan2(lr tan(delta), lf + lr),
+ *   x += (v cos(yaw) - v sin(yaw) beta) dt,  y += (v sin(yaw) + v cos(yaw) beta) dt,
+ *   yaw += (v beta / lr) dt,  v += a dt      (all from the values before the step).
+ *   state T[A][4] in/out;  u T[A][2] = a, delta;  beta_out T[A] optional (may be NULL).
+ */
+int sccbf_vehicle_step_f32(int64_t A, float* state, const float* u, double lr, double lf,
+                           double max_steer, double dt, float* beta_out, void* stream);
+int sccbf_vehicle_step_f64(int64_t A, double* state, const double* u, double lr, double lf,
+                           double max_steer, double dt, double* beta_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

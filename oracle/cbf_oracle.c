@@ -23,6 +23,7 @@
 #include <stdint.h>
 #include <stddef.h>
 #include <string.h>
+#include <stdlib.h>
 
 #define ORC_OBS_ELLIPSE 0
 #define ORC_OBS_CONE 1
@@ -539,4 +540,52 @@ double orc_stanley(const double s[4], int n, const double* cx, const double* cy,
     double theta_d = atan2(k * err, s[3] + ks);
     *idx_out = idx;
     return theta_e + theta_d;
+}
+
+/* Nominal input for a batch of agents on one shared course: Stanley steering as above and
+ * the scalar speed controller PID1.control, cbf/controllers.py:173-180 (e = target - v,
+ * de = (e - e_prev) / dt, ie += dt e, a = kp e + ki ie + kd de).
+ * traj is [N][4] = x, y, yaw, v_des; target_idx [A] in/out; pid_state [A][2] = e_prev, ie
+ * in/out or NULL (then a = kp e); u_ref [A][2] = a_ref, delta_ref. */
+void orc_nominal_batch(int64_t A, int32_t N, const double* state, const double* traj,
+                       int32_t* target_idx, double* pid_state, double axle, double k, double ks,
+                       double kp, double ki, double kd, double dt, double target_speed,
+                       double* u_ref)
+{
+    double* cx = (double*)malloc(sizeof(double) * 3 * (size_t)(N > 0 ? N : 1));
+    double* cy = cx + N;
+    double* cyaw = cy + N;
+    for (int i = 0; i < N; ++i) {
+        cx[i] = traj[4 * i];
+        cy[i] = traj[4 * i + 1];
+        cyaw[i] = traj[4 * i + 2];
+    }
+#pragma omp parallel for schedule(static)
+    for (int64_t a = 0; a < A; ++a) {
+        int idx = 0;
+        double delta = orc_stanley(state + 4 * a, N, cx, cy, cyaw, target_idx[a], axle, k, ks, &idx);
+        double e = target_speed - state[4 * a + 3];
+        double acc = kp * e;
+        if (pid_state) {
+            double de = (e - pid_state[2 * a]) / dt;
+            pid_state[2 * a + 1] += dt * e;
+            acc = kp * e + ki * pid_state[2 * a + 1] + kd * de;
+            pid_state[2 * a] = e;
+        }
+        target_idx[a] = idx;
+        u_ref[2 * a] = acc;
+        u_ref[2 * a + 1] = delta;
+    }
+    free(cx);
+}
+
+/* orc_vehicle_step over a batch: state [A][4] in place, u [A][2] = a, delta; beta [A] or NULL. */
+void orc_vehicle_step_batch(int64_t A, double* state, const double* u, double lr, double lf,
+                            double max_steer, double dt, double* beta)
+{
+#pragma omp parallel for schedule(static)
+    for (int64_t a = 0; a < A; ++a) {
+        double b = orc_vehicle_step(state + 4 * a, u[2 * a], u[2 * a + 1], lr, lf, max_steer, dt);
+        if (beta) beta[a] = b;
+    }
 }

@@ -75,6 +75,11 @@ def lib():
         L.orc_stanley.restype = C.c_double
         L.orc_stanley.argtypes = [dp, C.c_int, dp, dp, dp, C.c_int, C.c_double, C.c_double,
                                   C.c_double, C.POINTER(C.c_int)]
+        L.orc_nominal_batch.restype = None
+        L.orc_nominal_batch.argtypes = [C.c_int64, C.c_int32, dp, dp, C.POINTER(C.c_int32), dp] + \
+            [C.c_double] * 8 + [dp]
+        L.orc_vehicle_step_batch.restype = None
+        L.orc_vehicle_step_batch.argtypes = [C.c_int64, dp, dp] + [C.c_double] * 4 + [dp]
         _lib = L
     return _lib
 
@@ -163,3 +168,28 @@ def stanley(s, cx, cy, cyaw, last_idx, axle, k, ks=0.0):
     d = lib().orc_stanley(_dp(s), cx.size, _dp(cx), _dp(cy), _dp(cyaw), int(last_idx), axle, k, ks,
                           C.byref(idx))
     return d, idx.value
+
+
+def nominal_batch(state, traj, target_idx, pid_state=None, axle=2.9, k=0.5, ks=0.0, kp=1.0, ki=0.0,
+                  kd=0.0, dt=0.1, target_speed=30.0 / 3.6):
+    """Stanley + PID1 for a batch on one course.  state (A,4), traj (N,4) = x, y, yaw, v_des,
+    target_idx (A,) int32 and pid_state (A,2) are updated in place.  Returns u_ref (A,2)."""
+    state, traj = _f64(state), _f64(traj)
+    A, N = state.shape[0], traj.shape[0]
+    assert target_idx.dtype == np.int32 and target_idx.shape == (A,) and target_idx.flags.c_contiguous
+    if pid_state is not None:
+        assert pid_state.dtype == np.float64 and pid_state.shape == (A, 2) and pid_state.flags.c_contiguous
+    u = np.empty((A, 2))
+    lib().orc_nominal_batch(A, N, _dp(state), _dp(traj), target_idx.ctypes.data_as(C.POINTER(C.c_int32)),
+                            _dp(pid_state) if pid_state is not None else None, axle, k, ks, kp, ki, kd, dt,
+                            target_speed, _dp(u))
+    return u
+
+
+def vehicle_step_batch(state, u, lr, lf, max_steer, dt):
+    """In-place bicycle step on state (A,4) float64 with u (A,2) = a, delta; returns beta (A,)."""
+    assert state.dtype == np.float64 and state.flags.c_contiguous
+    u = _f64(u)
+    beta = np.empty(state.shape[0])
+    lib().orc_vehicle_step_batch(state.shape[0], _dp(state), _dp(u), lr, lf, max_steer, dt, _dp(beta))
+    return beta

@@ -16,7 +16,9 @@ ERR_ARG, ERR_ROWS, ERR_WEIGHT, ERR_LAUNCH, ERR_VARIANT, ERR_NO_DEVICE = -1, -2, 
 
 EXPORTS = ("sccbf_version", "sccbf_strerror", "sccbf_default_params", "sccbf_solve_f32",
            "sccbf_solve_f64", "sccbf_qp_f32", "sccbf_qp_f64", "sccbf_partials_f32",
-           "sccbf_partials_f64")
+           "sccbf_partials_f64", "sccbf_default_nominal_params", "sccbf_nominal_f32",
+           "sccbf_nominal_f64", "sccbf_vehicle_step_f32", "sccbf_vehicle_step_f64")
+NOMINAL_WAYPOINT_SPEED = 1
 
 
 class Params(C.Structure):
@@ -24,6 +26,13 @@ class Params(C.Structure):
     _fields_ = [("alpha", C.c_double), ("lr", C.c_double), ("lf", C.c_double), ("L", C.c_double),
                 ("R", C.c_double * 4), ("zero_tol", C.c_double), ("dynamics", C.c_int32),
                 ("lanes_per_qp", C.c_int32), ("flags", C.c_uint32), ("reserved", C.c_int32)]
+
+
+class NominalParams(C.Structure):
+    """struct sccbf_nominal_params of include/sccbf.h."""
+    _fields_ = [("axle", C.c_double), ("k", C.c_double), ("ks", C.c_double), ("kp", C.c_double),
+                ("ki", C.c_double), ("kd", C.c_double), ("dt", C.c_double), ("target_speed", C.c_double),
+                ("flags", C.c_uint32), ("reserved", C.c_int32)]
 
 
 class SccbfError(RuntimeError):
@@ -61,6 +70,16 @@ def load():
         f = getattr(L, name)
         f.restype = C.c_int
         f.argtypes = [C.POINTER(Params), C.c_int64, C.c_int32, vp, vp, vp, vp, vp]
+    L.sccbf_default_nominal_params.restype = None
+    L.sccbf_default_nominal_params.argtypes = [C.POINTER(NominalParams)]
+    for name in ("sccbf_nominal_f32", "sccbf_nominal_f64"):
+        f = getattr(L, name)
+        f.restype = C.c_int
+        f.argtypes = [C.POINTER(NominalParams), C.c_int64, C.c_int32, vp, vp, vp, vp, vp, vp]
+    for name in ("sccbf_vehicle_step_f32", "sccbf_vehicle_step_f64"):
+        f = getattr(L, name)
+        f.restype = C.c_int
+        f.argtypes = [C.c_int64, vp, vp, C.c_double, C.c_double, C.c_double, C.c_double, vp, vp]
     _lib = L
     return L
 

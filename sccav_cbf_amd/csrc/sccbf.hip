@@ -894,6 +894,118 @@ __global__ __launch_bounds__(kBlock) void k_passthrough(const KArgs<T> p)
     p.status[a] = ok ? SCCBF_STATUS_OPTIMAL : SCCBF_STATUS_NONFINITE;
 }
 
+// ------------------------------------------- nominal input: Stanley steering + PID speed
+template <typename T> struct NArgs {
+    T axle, k, ks, kp, ki, kd, dt, inv_dt, target_speed;
+    unsigned flags;
+    long long A;
+    int N;
+    const T* state;
+    const T* traj;
+    int* target_idx;
+    T* pid_state;
+    T* u_ref;
+};
+
+constexpr int kTrajChunk = 2048;  // way-points staged in LDS per pass
+
+template <typename T> __device__ inline T wrap_pi_(T a)
+{
+    // reference cbf/utils.py:93-106 subtracts / adds 2 pi until the angle is in [-pi, pi]
+    constexpr T kPi = T(3.14159265358979323846), k2Pi = T(6.28318530717958647692);
+    a -= k2Pi * rint(a * (T(1) / k2Pi));
+    a = a > kPi ? a - k2Pi : a;
+    a = a < -kPi ? a + k2Pi : a;
+    return a;
+}
+
+// One thread per agent; every thread scans the whole course, which the workgroup stages
+// through LDS chunk by chunk (all lanes read the same way-point: a broadcast read).
+// Squared distances order like the reference's np.hypot values (controllers.py:92-93).
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_nominal(const NArgs<T> p)
+{
+    using v4 = typename VT<T>::v4;
+    using v2 = typename VT<T>::v2;
+    __shared__ T s_x[kTrajChunk], s_y[kTrajChunk];
+    long long a = (long long)blockIdx.x * kBlock + threadIdx.x;
+    const bool live = a < p.A;
+    if (!live) a = p.A - 1;  // stays for the barriers; stores are masked
+    const v4* traj4 = reinterpret_cast<const v4*>(p.traj);
+    const v4 s = reinterpret_cast<const v4*>(p.state)[a];
+    T sth, cth;
+    sincos_(s.z, &sth, &cth);
+    const T fx = s.x + p.axle * cth, fy = s.y + p.axle * sth;
+    T best = INFINITY;
+    int bi = 0;
+    for (int base = 0; base < p.N; base += kTrajChunk) {
+        const int n = min(kTrajChunk, p.N - base);
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += kBlock) {
+            const v4 w = traj4[base + i];
+            s_x[i] = w.x;
+            s_y[i] = w.y;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int i = 0; i < n; ++i) {
+            const T dx = fx - s_x[i], dy = fy - s_y[i];
+            const T d = dx * dx + dy * dy;
+            const bool lt = d < best;  // strict: the first index wins a tie, like np.argmin
+            best = lt ? d : best;
+            bi = lt ? base + i : bi;
+        }
+    }
+    // cross-track error at the nearest way-point, projected on the axle direction
+    // (-cos(yaw + pi/2), -sin(yaw + pi/2)) = (sin yaw, -cos yaw): controllers.py:96-99
+    const v4 wn = traj4[bi];
+    const T err = (fx - wn.x) * sth - (fy - wn.y) * cth;
+    const int last = p.target_idx[a];
+    const int idx = last >= bi ? last : bi;  // controllers.py:118-119
+    const v4 wt = traj4[min(idx, p.N - 1)];
+    const T theta_e = wrap_pi_(wt.z - s.z);
+    const T theta_d = atan2_(p.k * err, s.w + p.ks);
+    const T vt = (p.flags & SCCBF_NOMINAL_WAYPOINT_SPEED) ? wt.w : p.target_speed;
+    const T e = vt - s.w;
+    T acc = p.kp * e;
+    if (p.pid_state) {
+        v2 ps = reinterpret_cast<v2*>(p.pid_state)[a];
+        const T de = (e - ps.x) * p.inv_dt;
+        ps.y += p.dt * e;
+        acc = p.kp * e + p.ki * ps.y + p.kd * de;
+        ps.x = e;
+        if (live) reinterpret_cast<v2*>(p.pid_state)[a] = ps;
+    }
+    if (live) {
+        p.target_idx[a] = idx;
+        reinterpret_cast<v2*>(p.u_ref)[a] = v2{acc, theta_e + theta_d};
+    }
+}
+
+// ------------------------------------------------------- vehicle step (update_com)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_vehicle_step(long long A, T* state, const T* u, T lr, T k_in,
+                                                         T inv_lr, T max_steer, T dt, T* beta_out)
+{
+    using v4 = typename VT<T>::v4;
+    using v2 = typename VT<T>::v2;
+    const long long a = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (a >= A) return;
+    v4 s = reinterpret_cast<v4*>(state)[a];
+    const v2 in = reinterpret_cast<const v2*>(u)[a];
+    const T delta = min_(max_(in.y, -max_steer), max_steer);
+    const T beta = atan_(tan_(delta) * k_in);  // atan2(lr tan(delta), lf + lr), lf + lr > 0
+    T sth, cth;
+    sincos_(s.z, &sth, &cth);
+    const T v = s.w;
+    s.x += (v * cth - v * sth * beta) * dt;
+    s.y += (v * sth + v * cth * beta) * dt;
+    s.z += (v * beta * inv_lr) * dt;
+    s.w += in.x * dt;
+    reinterpret_cast<v4*>(state)[a] = s;
+    if (beta_out) beta_out[a] = beta;
+}
+
 // ------------------------------------------------------------------- host side
 template <typename T>
 int fill_args(const sccbf_params* sp, int64_t A, int32_t M, KArgs<T>& k)
@@ -1064,6 +1176,42 @@ int qp_impl(const sccbf_params* sp, int64_t A, int32_t M, const T* rows, const T
     return dispatch<T, true>(&q, k, stream);
 }
 
+template <typename T>
+int nominal_impl(const sccbf_nominal_params* sp, int64_t A, int32_t N, const T* state, const T* traj,
+                 int32_t* target_idx, T* pid_state, T* u_ref, void* stream)
+{
+    if (!sp || A < 0 || N < 1 || A > 0x7fffffffLL) return SCCBF_ERR_ARG;
+    if (A == 0) return SCCBF_OK;
+    if (!state || !traj || !target_idx || !u_ref) return SCCBF_ERR_ARG;
+    if (pid_state && !(sp->dt > 0.0)) return SCCBF_ERR_ARG;
+    NArgs<T> k;
+    k.axle = (T)sp->axle; k.k = (T)sp->k; k.ks = (T)sp->ks;
+    k.kp = (T)sp->kp; k.ki = (T)sp->ki; k.kd = (T)sp->kd;
+    k.dt = (T)sp->dt; k.inv_dt = (T)(sp->dt > 0.0 ? 1.0 / sp->dt : 0.0);
+    k.target_speed = (T)sp->target_speed;
+    k.flags = sp->flags;
+    k.A = A; k.N = N;
+    k.state = state; k.traj = traj; k.target_idx = target_idx; k.pid_state = pid_state; k.u_ref = u_ref;
+    const long long blocks = (A + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL((k_nominal<T>), dim3((unsigned)blocks), dim3(kBlock), 0,
+                       reinterpret_cast<hipStream_t>(stream), k);
+    return hipGetLastError() == hipSuccess ? SCCBF_OK : SCCBF_ERR_LAUNCH;
+}
+
+template <typename T>
+int vehicle_step_impl(int64_t A, T* state, const T* u, double lr, double lf, double max_steer, double dt,
+                      T* beta_out, void* stream)
+{
+    if (A < 0 || A > 0x7fffffffLL || !(lr > 0.0) || !(lf + lr > 0.0) || !(max_steer >= 0.0)) return SCCBF_ERR_ARG;
+    if (A == 0) return SCCBF_OK;
+    if (!state || !u) return SCCBF_ERR_ARG;
+    const long long blocks = (A + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL((k_vehicle_step<T>), dim3((unsigned)blocks), dim3(kBlock), 0,
+                       reinterpret_cast<hipStream_t>(stream), (long long)A, state, u, (T)lr,
+                       (T)(lr / (lf + lr)), (T)(1.0 / lr), (T)max_steer, (T)dt, beta_out);
+    return hipGetLastError() == hipSuccess ? SCCBF_OK : SCCBF_ERR_LAUNCH;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1135,6 +1283,45 @@ int sccbf_partials_f64(const sccbf_params* p, int64_t A, int32_t M, const double
                        const double* obs, const uint8_t* obs_type, double* out, void* stream)
 {
     return partials_impl<double>(p, A, M, state, obs, obs_type, out, stream);
+}
+
+void sccbf_default_nominal_params(sccbf_nominal_params* p)
+{
+    if (!p) return;
+    p->axle = 2.0;
+    p->k = 0.5;
+    p->ks = 0.01;
+    p->kp = 1.0;
+    p->ki = 0.0;
+    p->kd = 0.0;
+    p->dt = 0.1;
+    p->target_speed = 30.0 / 3.6;
+    p->flags = 0;
+    p->reserved = 0;
+}
+
+int sccbf_nominal_f32(const sccbf_nominal_params* p, int64_t A, int32_t N, const float* state,
+                      const float* traj, int32_t* target_idx, float* pid_state, float* u_ref, void* stream)
+{
+    return nominal_impl<float>(p, A, N, state, traj, target_idx, pid_state, u_ref, stream);
+}
+
+int sccbf_nominal_f64(const sccbf_nominal_params* p, int64_t A, int32_t N, const double* state,
+                      const double* traj, int32_t* target_idx, double* pid_state, double* u_ref, void* stream)
+{
+    return nominal_impl<double>(p, A, N, state, traj, target_idx, pid_state, u_ref, stream);
+}
+
+int sccbf_vehicle_step_f32(int64_t A, float* state, const float* u, double lr, double lf, double max_steer,
+                           double dt, float* beta_out, void* stream)
+{
+    return vehicle_step_impl<float>(A, state, u, lr, lf, max_steer, dt, beta_out, stream);
+}
+
+int sccbf_vehicle_step_f64(int64_t A, double* state, const double* u, double lr, double lf, double max_steer,
+                           double dt, double* beta_out, void* stream)
+{
+    return vehicle_step_impl<double>(A, state, u, lr, lf, max_steer, dt, beta_out, stream);
 }
 
 }  // extern "C"

@@ -1,0 +1,122 @@
+"""Batched nominal controller, vehicle step and closed-loop rollout around the filter.
+
+BatchedNominal  Stanley steering + PID speed control for every agent of a batch on one shared
+                course (the per-ego objects of reference cbf/controllers.py:17-180; the driver
+                scripts restate the law in test_scripts/stanley_controller_ellipse.py:146-212).
+vehicle_step    State.update_com of the drivers (stanley_controller_ellipse.py:122-131).
+ClosedLoop      nominal -> filter -> vehicle step, tick after tick, without leaving the GPU
+                (the main loop of stanley_controller_ellipse.py:700-760 for a whole batch).
+
+All arithmetic is in libsccbf.so; tensors hold device memory and the current stream.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .batched import BatchedCBF, _ptr
+
+
+def _check(name, t, shape, dtype, dev):
+    if tuple(t.shape) != tuple(shape) or t.dtype != dtype or t.device != dev or not t.is_contiguous():
+        raise ValueError("%s: expected contiguous %s %s on %s, got %s %s on %s" % (
+            name, tuple(shape), dtype, dev, tuple(t.shape), t.dtype, t.device))
+
+
+class BatchedNominal:
+    """u_ref = (a_ref, delta_ref) for A agents following one course.
+
+    axle is the distance from the state's reference point to the front axle: lf for
+    LateralStanley (cbf/controllers.py:80-81), the wheel base for the driver scripts."""
+
+    def __init__(self, axle=2.0, k=0.5, ks=0.01, kp=1.0, ki=0.0, kd=0.0, dt=0.1,
+                 target_speed=30.0 / 3.6, waypoint_speed=False):
+        self._lib = _lib.load()
+        self.params = _lib.NominalParams()
+        self._lib.sccbf_default_nominal_params(C.byref(self.params))
+        self.params.axle, self.params.k, self.params.ks = float(axle), float(k), float(ks)
+        self.params.kp, self.params.ki, self.params.kd = float(kp), float(ki), float(kd)
+        self.params.dt = float(dt)
+        self.params.target_speed = float(target_speed)
+        self.params.flags = _lib.NOMINAL_WAYPOINT_SPEED if waypoint_speed else 0
+
+    def set_gains(self, k=None, ks=None, kp=None, ki=None, kd=None):
+        for name, v in (("k", k), ("ks", ks), ("kp", kp), ("ki", ki), ("kd", kd)):
+            if v is not None:
+                setattr(self.params, name, float(v))
+
+    def control(self, state, traj, target_idx, pid_state=None, u_ref=None):
+        """state (A,4), traj (N,4) = x, y, yaw, v_des, target_idx (A,) int32 (updated in place),
+        pid_state (A,2) = previous error, integral (updated in place; None = P control).
+        Returns u_ref (A,2).  Asynchronous on the current stream."""
+        if not state.is_cuda:
+            raise _lib.SccbfError("BatchedNominal.control needs tensors on the GPU (no CPU fallback)")
+        dt, dev = state.dtype, state.device
+        if dt not in (torch.float32, torch.float64):
+            raise ValueError("state must be float32 or float64")
+        A, N = state.shape[0], traj.shape[0]
+        if N < 1:
+            raise ValueError("the course needs at least one way-point")
+        _check("state", state, (A, 4), dt, dev)
+        _check("traj", traj, (N, 4), dt, dev)
+        _check("target_idx", target_idx, (A,), torch.int32, dev)
+        if pid_state is not None:
+            _check("pid_state", pid_state, (A, 2), dt, dev)
+        if u_ref is None:
+            u_ref = torch.empty((A, 2), dtype=dt, device=dev)
+        _check("u_ref", u_ref, (A, 2), dt, dev)
+        fn = self._lib.sccbf_nominal_f32 if dt == torch.float32 else self._lib.sccbf_nominal_f64
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            rc = fn(C.byref(self.params), A, N, _ptr(state), _ptr(traj), _ptr(target_idx), _ptr(pid_state),
+                    _ptr(u_ref), C.c_void_p(stream))
+        _lib.check(rc)
+        return u_ref
+
+
+def vehicle_step(state, u, lr=1.45, lf=1.45, max_steer=np.radians(30.0), dt=0.1, beta_out=None):
+    """In-place bicycle step of state (A,4) with u (A,2) = a, delta; beta_out (A,) optional."""
+    if not state.is_cuda:
+        raise _lib.SccbfError("vehicle_step needs tensors on the GPU (no CPU fallback)")
+    ty, dev = state.dtype, state.device
+    A = state.shape[0]
+    _check("state", state, (A, 4), ty, dev)
+    _check("u", u, (A, 2), ty, dev)
+    if beta_out is not None:
+        _check("beta_out", beta_out, (A,), ty, dev)
+    lib = _lib.load()
+    fn = lib.sccbf_vehicle_step_f32 if ty == torch.float32 else lib.sccbf_vehicle_step_f64
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        rc = fn(A, _ptr(state), _ptr(u), float(lr), float(lf), float(max_steer), float(dt), _ptr(beta_out),
+                C.c_void_p(stream))
+    _lib.check(rc)
+    return state
+
+
+class ClosedLoop:
+    """nominal -> filter -> vehicle step for a batch, every tensor resident on the GPU.
+
+    tick() launches three kernels on the current stream and allocates nothing, so a caller may
+    capture a number of ticks in a hipGraph.  Obstacles are whatever `obs` holds when the tick
+    runs: move them between ticks (or inside the captured region) with ordinary tensor ops."""
+
+    def __init__(self, cbf: BatchedCBF, nominal: BatchedNominal, traj, state, obs, obs_type,
+                 max_steer=np.radians(30.0), dt=0.1, use_pid_state=False):
+        self.cbf, self.nominal = cbf, nominal
+        self.traj, self.state, self.obs, self.obs_type = traj, state, obs, obs_type
+        self.max_steer, self.dt = float(max_steer), float(dt)
+        A, dev, ty = state.shape[0], state.device, state.dtype
+        self.target_idx = torch.zeros((A,), dtype=torch.int32, device=dev)
+        self.pid_state = torch.zeros((A, 2), dtype=ty, device=dev) if use_pid_state else None
+        self.u_ref = torch.empty((A, 2), dtype=ty, device=dev)
+        self.u = torch.empty((A, 2), dtype=ty, device=dev)
+        self.status = torch.empty((A,), dtype=torch.int32, device=dev)
+        self.beta = torch.empty((A,), dtype=ty, device=dev)
+
+    def tick(self):
+        self.nominal.control(self.state, self.traj, self.target_idx, self.pid_state, u_ref=self.u_ref)
+        self.cbf.solve(self.state, self.u_ref, self.obs, self.obs_type, u_out=self.u, status=self.status)
+        vehicle_step(self.state, self.u, lr=self.cbf.params.lr, lf=self.cbf.params.lf,
+                     max_steer=self.max_steer, dt=self.dt, beta_out=self.beta)

@@ -73,6 +73,22 @@ def test_host_side_argument_validation(lib):
     assert lib.sccbf_solve_f32(C.byref(p), 1, 1, *args) == -1
 
 
+def test_nominal_and_vehicle_step_argument_validation(lib):
+    assert C.sizeof(_lib.NominalParams) == 8 * 8 + 2 * 4
+    q = _lib.NominalParams()
+    lib.sccbf_default_nominal_params(C.byref(q))
+    assert (q.axle, q.k, q.ks, q.kp, q.ki, q.kd, q.dt) == (2.0, 0.5, 0.01, 1.0, 0.0, 0.0, 0.1)
+    assert abs(q.target_speed - 30.0 / 3.6) < 1e-15 and q.flags == 0
+    nul = C.c_void_p(0)
+    assert lib.sccbf_nominal_f32(None, 1, 1, nul, nul, nul, nul, nul, nul) == -1
+    assert lib.sccbf_nominal_f32(C.byref(q), 1, 0, nul, nul, nul, nul, nul, nul) == -1     # empty course
+    assert lib.sccbf_nominal_f64(C.byref(q), 0, 5, nul, nul, nul, nul, nul, nul) == 0      # empty batch
+    assert lib.sccbf_nominal_f64(C.byref(q), 3, 5, nul, nul, nul, nul, nul, nul) == -1     # null data
+    assert lib.sccbf_vehicle_step_f32(0, nul, nul, 1.45, 1.45, 0.5, 0.1, nul, nul) == 0
+    assert lib.sccbf_vehicle_step_f32(2, nul, nul, 1.45, 1.45, 0.5, 0.1, nul, nul) == -1
+    assert lib.sccbf_vehicle_step_f64(2, nul, nul, 0.0, 1.45, 0.5, 0.1, nul, nul) == -1    # lr must be > 0
+
+
 def test_no_cpu_fallback_in_front_end():
     """Without a GPU the batched front-end must refuse, not compute somewhere else."""
     import numpy as np
@@ -84,3 +100,8 @@ def test_no_cpu_fallback_in_front_end():
     z = torch.zeros((1, 4))
     with pytest.raises(_lib.SccbfError):
         f.solve(z, torch.zeros((1, 2)), torch.zeros((1, 2, 1, 4)), torch.zeros((1,), dtype=torch.uint8))
+    from sccav_cbf_amd.nominal import BatchedNominal, vehicle_step
+    with pytest.raises(_lib.SccbfError):
+        BatchedNominal().control(z, torch.zeros((3, 4)), torch.zeros((1,), dtype=torch.int32))
+    with pytest.raises(_lib.SccbfError):
+        vehicle_step(z, torch.zeros((1, 2)))
