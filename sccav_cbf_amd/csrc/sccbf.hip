@@ -908,6 +908,9 @@ template <typename T> struct NArgs {
 };
 
 constexpr int kTrajChunk = 2048;  // way-points staged in LDS per pass
+constexpr int kSub = 32;          // way-points per bounding box
+constexpr int kSubs = kTrajChunk / kSub;
+static_assert(kBlock * 8 == kTrajChunk && kSub == 4 * 8, "staging below: 8 points per thread, 4 threads per box");
 
 template <typename T> __device__ inline T wrap_pi_(T a)
 {
@@ -919,16 +922,37 @@ template <typename T> __device__ inline T wrap_pi_(T a)
     return a;
 }
 
-// One thread per agent; every thread scans the whole course, which the workgroup stages
-// through LDS chunk by chunk (all lanes read the same way-point: a broadcast read).
-// Squared distances order like the reference's np.hypot values (controllers.py:92-93).
+template <typename T> __device__ inline T quad_min_(T v)
+{
+    v = min_(v, __shfl_xor(v, 1, 64));
+    return min_(v, __shfl_xor(v, 2, 64));
+}
+template <typename T> __device__ inline T quad_max_(T v)
+{
+    v = max_(v, __shfl_xor(v, 1, 64));
+    return max_(v, __shfl_xor(v, 2, 64));
+}
+
+// Four lanes per agent.  The nearest way-point is searched over the whole course
+// (controllers.py:89-93: np.argmin of np.hypot, first index on ties; squared distances order
+// the same way), exactly but not exhaustively: the workgroup stages the course through LDS
+// 2048 way-points at a time together with the bounding box of every run of 32.  The distance
+// to last tick's target way-point bounds the answer from above; the four lanes step through
+// the boxes four at a time and scan (eight way-points each) only the runs whose box is not
+// farther than the best distance known so far.  Every group walks its own list of runs, so a
+// wavefront pays for the longest list among its groups, not for their union.
+constexpr int kNomLanes = 4;
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_nominal(const NArgs<T> p)
 {
     using v4 = typename VT<T>::v4;
     using v2 = typename VT<T>::v2;
-    __shared__ T s_x[kTrajChunk], s_y[kTrajChunk];
-    long long a = (long long)blockIdx.x * kBlock + threadIdx.x;
+    constexpr int G = kNomLanes;
+    constexpr int kStride = kSub + 1;  // odd stride: groups scanning different runs hit different banks
+    __shared__ T s_x[kSubs * kStride], s_y[kSubs * kStride];
+    __shared__ T s_x0[kSubs + G], s_x1[kSubs + G], s_y0[kSubs + G], s_y1[kSubs + G];
+    const int g = threadIdx.x % G;
+    long long a = (long long)blockIdx.x * (kBlock / G) + threadIdx.x / G;
     const bool live = a < p.A;
     if (!live) a = p.A - 1;  // stays for the barriers; stores are masked
     const v4* traj4 = reinterpret_cast<const v4*>(p.traj);
@@ -936,31 +960,88 @@ __global__ __launch_bounds__(kBlock) void k_nominal(const NArgs<T> p)
     T sth, cth;
     sincos_(s.z, &sth, &cth);
     const T fx = s.x + p.axle * cth, fy = s.y + p.axle * sth;
-    T best = INFINITY;
-    int bi = 0;
+    const int last = p.target_idx[a];
+    // upper bound of the answer: the distance to the way-point targeted last tick
+    T lim;
+    {
+        const v2 wl = *reinterpret_cast<const v2*>(traj4 + min(max(last, 0), p.N - 1));
+        lim = (fx - wl.x) * (fx - wl.x) + (fy - wl.y) * (fy - wl.y);
+    }
+    T best = INFINITY;  // of this lane's way-points; strict "<" in index order: first index on ties
+    int bi = 0x7fffffff;
+
+    if (threadIdx.x < G) {  // boxes past the last run (read by the four-at-a-time walk): empty
+        s_x0[kSubs + threadIdx.x] = INFINITY; s_x1[kSubs + threadIdx.x] = -INFINITY;
+        s_y0[kSubs + threadIdx.x] = INFINITY; s_y1[kSubs + threadIdx.x] = -INFINITY;
+    }
     for (int base = 0; base < p.N; base += kTrajChunk) {
         const int n = min(kTrajChunk, p.N - base);
         __syncthreads();
-        for (int i = threadIdx.x; i < n; i += kBlock) {
-            const v4 w = traj4[base + i];
-            s_x[i] = w.x;
-            s_y[i] = w.y;
+        {   // stage: thread t takes way-points 8 t .. 8 t + 7, four threads make one run of 32
+            T x0 = INFINITY, x1 = -INFINITY, y0 = INFINITY, y1 = -INFINITY;
+            const int r = threadIdx.x / 4, j0 = (threadIdx.x % 4) * 8;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int i = threadIdx.x * 8 + j;
+                T x = INFINITY, y = INFINITY;  // past the end: never the nearest
+                if (i < n) {
+                    const v2 w = *reinterpret_cast<const v2*>(traj4 + base + i);
+                    x = w.x; y = w.y;
+                    x0 = min_(x0, x); x1 = max_(x1, x);
+                    y0 = min_(y0, y); y1 = max_(y1, y);
+                }
+                s_x[r * kStride + j0 + j] = x;
+                s_y[r * kStride + j0 + j] = y;
+            }
+            x0 = quad_min_(x0); x1 = quad_max_(x1);
+            y0 = quad_min_(y0); y1 = quad_max_(y1);
+            if (threadIdx.x % 4 == 0) {
+                s_x0[r] = x0; s_x1[r] = x1; s_y0[r] = y0; s_y1[r] = y1;
+            }
         }
         __syncthreads();
-#pragma unroll 8
-        for (int i = 0; i < n; ++i) {
-            const T dx = fx - s_x[i], dy = fy - s_y[i];
-            const T d = dx * dx + dy * dy;
-            const bool lt = d < best;  // strict: the first index wins a tie, like np.argmin
-            best = lt ? d : best;
-            bi = lt ? base + i : bi;
+        const int runs = (n + kSub - 1) / kSub;
+        for (int r = 0; r < runs;) {  // r and lim are the same in the four lanes of a group
+            // lane g looks at the box of run r + g (infinitely far when the run is empty)
+            const T dx = max_(max_(s_x0[r + g] - fx, fx - s_x1[r + g]), T(0));
+            const T dy = max_(max_(s_y0[r + g] - fy, fy - s_y1[r + g]), T(0));
+            // (a few ulps of slack: the box distance and the way-point distance round independently)
+            const unsigned hit = group_or<G>((dx * dx + dy * dy <= lim * (T(1) + T(8) * Lim<T>::eps)) ? 1u << g : 0u);
+            if (hit == 0u) {
+                r += G;
+                continue;
+            }
+            r += __ffs(hit) - 1;  // the first run of the four that can hold the answer
+#pragma unroll
+            for (int j = 0; j < kSub / G; ++j) {  // lane g: way-points 8 g .. 8 g + 7 of the run
+                const int jj = g * (kSub / G) + j;
+                const T ex = fx - s_x[r * kStride + jj], ey = fy - s_y[r * kStride + jj];
+                const T d = ex * ex + ey * ey;
+                const bool lt = d < best;
+                best = lt ? d : best;
+                bi = lt ? base + r * kSub + jj : bi;
+            }
+            // tighten the bound with the group's best so far
+            T m = best;
+            m = min_(m, __shfl_xor(m, 1, 64));
+            m = min_(m, __shfl_xor(m, 2, 64));
+            lim = min_(lim, m);
+            ++r;
         }
+    }
+    {   // the group's answer: least distance, then least index
+        T m = best;
+        m = min_(m, __shfl_xor(m, 1, 64));
+        m = min_(m, __shfl_xor(m, 2, 64));
+        int c = best == m ? bi : 0x7fffffff;
+        c = min(c, __shfl_xor(c, 1, 64));
+        c = min(c, __shfl_xor(c, 2, 64));
+        bi = min(c, p.N - 1);  // (non-finite state: no way-point compares nearer; any index will do)
     }
     // cross-track error at the nearest way-point, projected on the axle direction
     // (-cos(yaw + pi/2), -sin(yaw + pi/2)) = (sin yaw, -cos yaw): controllers.py:96-99
     const v4 wn = traj4[bi];
     const T err = (fx - wn.x) * sth - (fy - wn.y) * cth;
-    const int last = p.target_idx[a];
     const int idx = last >= bi ? last : bi;  // controllers.py:118-119
     const v4 wt = traj4[min(idx, p.N - 1)];
     const T theta_e = wrap_pi_(wt.z - s.z);
@@ -974,9 +1055,9 @@ __global__ __launch_bounds__(kBlock) void k_nominal(const NArgs<T> p)
         ps.y += p.dt * e;
         acc = p.kp * e + p.ki * ps.y + p.kd * de;
         ps.x = e;
-        if (live) reinterpret_cast<v2*>(p.pid_state)[a] = ps;
+        if (live && g == 0) reinterpret_cast<v2*>(p.pid_state)[a] = ps;
     }
-    if (live) {
+    if (live && g == 0) {
         p.target_idx[a] = idx;
         reinterpret_cast<v2*>(p.u_ref)[a] = v2{acc, theta_e + theta_d};
     }
@@ -1192,7 +1273,8 @@ int nominal_impl(const sccbf_nominal_params* sp, int64_t A, int32_t N, const T* 
     k.flags = sp->flags;
     k.A = A; k.N = N;
     k.state = state; k.traj = traj; k.target_idx = target_idx; k.pid_state = pid_state; k.u_ref = u_ref;
-    const long long blocks = (A + kBlock - 1) / kBlock;
+    const long long per_block = kBlock / kNomLanes;
+    const long long blocks = (A + per_block - 1) / per_block;
     hipLaunchKernelGGL((k_nominal<T>), dim3((unsigned)blocks), dim3(kBlock), 0,
                        reinterpret_cast<hipStream_t>(stream), k);
     return hipGetLastError() == hipSuccess ? SCCBF_OK : SCCBF_ERR_LAUNCH;

@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""Time the nominal controller, the filter, the vehicle step and a captured closed-loop tick.
+
+    python tools/bench_closed_loop.py [--agents 65536] [--dtype f32]
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import replay  # noqa: E402  (course fixture only)
+from sccav_cbf_amd import scenarios  # noqa: E402
+from sccav_cbf_amd.batched import BatchedCBF, planes_to_tiled  # noqa: E402
+from sccav_cbf_amd.nominal import BatchedNominal, ClosedLoop, vehicle_step  # noqa: E402
+
+
+def timed(fn, reps):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / reps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--agents", type=int, default=65536)
+    ap.add_argument("--dtype", default="f32")
+    args = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    dt = torch.float32 if args.dtype == "f32" else torch.float64
+    A = args.agents
+    cx, cy, cyaw = replay.load_course()
+    traj = torch.from_numpy(np.stack([cx, cy, cyaw, np.full_like(cx, 30 / 3.6)], axis=1)).to(dt).to(dev)
+    w = scenarios.config4(A=A, seed=1)
+    # agents start within a few metres of the course (the closed-loop use case); the obstacles of the
+    # C4 batch keep their position relative to their agent
+    rng = np.random.default_rng(2)
+    at = rng.integers(0, len(cx), A)
+    xy = np.stack([cx[at] + rng.normal(0, 3, A), cy[at] + rng.normal(0, 3, A)], axis=1)
+    w["obs"][:, 0, :, 0:2] += (xy - w["state"][:, 0:2])[None, :, :]
+    w["state"][:, 0:2] = xy
+    w["state"][:, 2] = cyaw[at] + rng.normal(0, 0.3, A)
+    state = torch.from_numpy(w["state"]).to(dt).to(dev)
+    state0 = state.clone()
+    obs = planes_to_tiled(torch.from_numpy(w["obs"]).to(dt).to(dev))
+    ty = torch.from_numpy(w["obs_type"]).to(dev)
+    cbf = BatchedCBF(alpha=1.0, R=np.diag([0.5, 0.5]))
+    nom = BatchedNominal(axle=2.9, k=0.5, ks=0.0)
+    loop = ClosedLoop(cbf, nom, traj, state, obs, ty)
+    st = torch.cuda.Stream(dev)
+    with torch.cuda.stream(st):
+        loop.state.copy_(state0)
+        t_nom = timed(lambda: nom.control(loop.state, traj, loop.target_idx, None, u_ref=loop.u_ref), 200)
+        t_flt = timed(lambda: cbf.solve(loop.state, loop.u_ref, obs, ty, u_out=loop.u, status=loop.status), 200)
+        t_stp = timed(lambda: vehicle_step(loop.state, loop.u, beta_out=loop.beta), 200)
+        loop.tick()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=st):
+            loop.state.copy_(state0)        # every replay starts from the same states
+            loop.target_idx.zero_()
+            for _ in range(10):
+                loop.tick()
+        t_tick = timed(g.replay, 50) / 10
+    print("A=%d N=%d %s: nominal %.2f us, filter %.2f us, vehicle step %.2f us, captured tick %.2f us "
+          "(%.3e agent-ticks/s)" % (A, traj.shape[0], args.dtype, t_nom, t_flt, t_stp, t_tick, A / (t_tick * 1e-6)))
+
+
+if __name__ == "__main__":
+    main()
