@@ -910,7 +910,8 @@ template <typename T> struct NArgs {
 constexpr int kTrajChunk = 2048;  // way-points staged in LDS per pass
 constexpr int kSub = 32;          // way-points per bounding box
 constexpr int kSubs = kTrajChunk / kSub;
-static_assert(kBlock * 8 == kTrajChunk && kSub == 4 * 8, "staging below: 8 points per thread, 4 threads per box");
+constexpr int kNomBlock = 1024;   // threads per workgroup of the nominal kernel: 256 agents share one staging
+static_assert(kNomBlock * 2 == kTrajChunk && kSub == 16 * 2, "staging below: 2 points per thread, 16 threads per box");
 
 template <typename T> __device__ inline T wrap_pi_(T a)
 {
@@ -922,15 +923,17 @@ template <typename T> __device__ inline T wrap_pi_(T a)
     return a;
 }
 
-template <typename T> __device__ inline T quad_min_(T v)
+template <typename T> __device__ inline T row16_min_(T v)  // over 16 consecutive lanes
 {
-    v = min_(v, __shfl_xor(v, 1, 64));
-    return min_(v, __shfl_xor(v, 2, 64));
+#pragma unroll
+    for (int m = 1; m < 16; m *= 2) v = min_(v, __shfl_xor(v, m, 64));
+    return v;
 }
-template <typename T> __device__ inline T quad_max_(T v)
+template <typename T> __device__ inline T row16_max_(T v)
 {
-    v = max_(v, __shfl_xor(v, 1, 64));
-    return max_(v, __shfl_xor(v, 2, 64));
+#pragma unroll
+    for (int m = 1; m < 16; m *= 2) v = max_(v, __shfl_xor(v, m, 64));
+    return v;
 }
 
 // Four lanes per agent.  The nearest way-point is searched over the whole course
@@ -943,7 +946,7 @@ template <typename T> __device__ inline T quad_max_(T v)
 // wavefront pays for the longest list among its groups, not for their union.
 constexpr int kNomLanes = 4;
 template <typename T>
-__global__ __launch_bounds__(kBlock) void k_nominal(const NArgs<T> p)
+__global__ __launch_bounds__(kNomBlock) void k_nominal(const NArgs<T> p)
 {
     using v4 = typename VT<T>::v4;
     using v2 = typename VT<T>::v2;
@@ -952,7 +955,7 @@ __global__ __launch_bounds__(kBlock) void k_nominal(const NArgs<T> p)
     __shared__ T s_x[kSubs * kStride], s_y[kSubs * kStride];
     __shared__ T s_x0[kSubs + G], s_x1[kSubs + G], s_y0[kSubs + G], s_y1[kSubs + G];
     const int g = threadIdx.x % G;
-    long long a = (long long)blockIdx.x * (kBlock / G) + threadIdx.x / G;
+    long long a = (long long)blockIdx.x * (kNomBlock / G) + threadIdx.x / G;
     const bool live = a < p.A;
     if (!live) a = p.A - 1;  // stays for the barriers; stores are masked
     const v4* traj4 = reinterpret_cast<const v4*>(p.traj);
@@ -977,12 +980,12 @@ __global__ __launch_bounds__(kBlock) void k_nominal(const NArgs<T> p)
     for (int base = 0; base < p.N; base += kTrajChunk) {
         const int n = min(kTrajChunk, p.N - base);
         __syncthreads();
-        {   // stage: thread t takes way-points 8 t .. 8 t + 7, four threads make one run of 32
+        {   // stage: thread t takes way-points 2 t, 2 t + 1; sixteen threads make one run of 32
             T x0 = INFINITY, x1 = -INFINITY, y0 = INFINITY, y1 = -INFINITY;
-            const int r = threadIdx.x / 4, j0 = (threadIdx.x % 4) * 8;
+            const int r = threadIdx.x / 16, j0 = (threadIdx.x % 16) * 2;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int i = threadIdx.x * 8 + j;
+            for (int j = 0; j < 2; ++j) {
+                const int i = threadIdx.x * 2 + j;
                 T x = INFINITY, y = INFINITY;  // past the end: never the nearest
                 if (i < n) {
                     const v2 w = *reinterpret_cast<const v2*>(traj4 + base + i);
@@ -993,9 +996,9 @@ __global__ __launch_bounds__(kBlock) void k_nominal(const NArgs<T> p)
                 s_x[r * kStride + j0 + j] = x;
                 s_y[r * kStride + j0 + j] = y;
             }
-            x0 = quad_min_(x0); x1 = quad_max_(x1);
-            y0 = quad_min_(y0); y1 = quad_max_(y1);
-            if (threadIdx.x % 4 == 0) {
+            x0 = row16_min_(x0); x1 = row16_max_(x1);
+            y0 = row16_min_(y0); y1 = row16_max_(y1);
+            if (threadIdx.x % 16 == 0) {
                 s_x0[r] = x0; s_x1[r] = x1; s_y0[r] = y0; s_y1[r] = y1;
             }
         }
@@ -1273,9 +1276,9 @@ int nominal_impl(const sccbf_nominal_params* sp, int64_t A, int32_t N, const T* 
     k.flags = sp->flags;
     k.A = A; k.N = N;
     k.state = state; k.traj = traj; k.target_idx = target_idx; k.pid_state = pid_state; k.u_ref = u_ref;
-    const long long per_block = kBlock / kNomLanes;
+    const long long per_block = kNomBlock / kNomLanes;
     const long long blocks = (A + per_block - 1) / per_block;
-    hipLaunchKernelGGL((k_nominal<T>), dim3((unsigned)blocks), dim3(kBlock), 0,
+    hipLaunchKernelGGL((k_nominal<T>), dim3((unsigned)blocks), dim3(kNomBlock), 0,
                        reinterpret_cast<hipStream_t>(stream), k);
     return hipGetLastError() == hipSuccess ? SCCBF_OK : SCCBF_ERR_LAUNCH;
 }
