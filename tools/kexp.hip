@@ -40,8 +40,12 @@ template <int G, int RPL, int VAR>
 __global__ __launch_bounds__(256) void k_loadonly(const KArgs<float> p)
 {
     const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
-    const long long qp = gid / G;
-    const int g = (int)(gid % G);
+    long long qp = gid / G;
+    int g = (int)(gid % G);
+    if (VAR == 7) {  // G = 4 only: lane = QP of the tile, wave w owns slots 4 w .. 4 w + 3
+        qp = (long long)blockIdx.x * 64 + (threadIdx.x & 63);
+        g = threadIdx.x >> 6;
+    }
     if (qp >= p.A) return;
     const float4* obs4 = reinterpret_cast<const float4*>(p.obs);
     float4 oa[RPL], ob[RPL];
@@ -52,6 +56,15 @@ __global__ __launch_bounds__(256) void k_loadonly(const KArgs<float> p)
         if (VAR == 5) {  // slot groups interleaved: one contiguous KiB per wave instruction
             i0 = ((long long)(r * 2) * p.A + qp) * G + g;
             i1 = ((long long)(r * 2 + 1) * p.A + qp) * G + g;
+        }
+        if (VAR == 8) {  // [A/16][M][16][2] float4: slot halves adjacent, one wave instruction pair = 2 KiB in one piece
+            i0 = (qp >> 4) * (long long)(p.M * 32) + (long long)m * 32 + (qp & 15) * 2;
+            i1 = i0 + 1;
+        }
+        if (VAR == 7) {  // a wave reads 8 KiB of its tile in one piece
+            const long long tb = (qp >> 6) * (long long)(p.M * 2 * 64) + (qp & 63);
+            i0 = tb + (long long)((g * RPL + r) * 2) * 64;
+            i1 = i0 + 64;
         }
         if (VAR == 6) {  // tiles of 64 agents: [A/64][M][2][64] float4
             const long long tb = (qp >> 6) * (long long)(p.M * 2 * 64) + (qp & 63);
@@ -69,8 +82,10 @@ __global__ __launch_bounds__(256) void k_loadonly(const KArgs<float> p)
     }
 #pragma unroll
     for (int r = 0; r < RPL; ++r) acc += oa[r].x + oa[r].y + oa[r].z + oa[r].w + ob[r].x + ob[r].y + ob[r].z + ob[r].w;
-    acc = __uint_as_float(group_umax<G>(__float_as_uint(acc)));
-    if (VAR >= 3) {
+    if (VAR != 7) acc = __uint_as_float(group_umax<G>(__float_as_uint(acc)));
+    if (VAR == 7) {
+        if (g == 0 || acc == 123.456f) { reinterpret_cast<float2*>(p.u_out)[qp] = float2{acc, acc}; p.status[qp] = 0; }
+    } else if (VAR >= 3) {
         if ((threadIdx.x & 63) == 0) { reinterpret_cast<float2*>(p.u_out)[qp] = float2{acc, acc}; p.status[qp] = 0; }
     } else if (g == 0) {
         reinterpret_cast<float2*>(p.u_out)[qp] = float2{acc, acc};
@@ -212,6 +227,8 @@ int main(int argc, char** argv)
     report("loadonly G=" #G, time_it([&](int b) { setk(b); hipLaunchKernelGGL((k_loadonly<G, RPL, 0>), dim3((unsigned)((A * G + 255) / 256)), dim3(256), 0, 0, k); }, ITERS, RING)); \
     report("loadonly G=" #G " interleaved", time_it([&](int b) { setk(b); hipLaunchKernelGGL((k_loadonly<G, RPL, 5>), dim3((unsigned)((A * G + 255) / 256)), dim3(256), 0, 0, k); }, ITERS, RING)); \
     report("loadonly G=" #G " tiles64", time_it([&](int b) { setk(b); hipLaunchKernelGGL((k_loadonly<G, RPL, 6>), dim3((unsigned)((A * G + 255) / 256)), dim3(256), 0, 0, k); }, ITERS, RING)); \
+    report("loadonly G=" #G " wave-contiguous", time_it([&](int b) { setk(b); hipLaunchKernelGGL((k_loadonly<G, RPL, 7>), dim3((unsigned)((A * G + 255) / 256)), dim3(256), 0, 0, k); }, ITERS, RING)); \
+    report("loadonly G=" #G " tile16 slot32", time_it([&](int b) { setk(b); hipLaunchKernelGGL((k_loadonly<G, RPL, 8>), dim3((unsigned)((A * G + 255) / 256)), dim3(256), 0, 0, k); }, ITERS, RING)); \
     report("loadonly G=" #G " slots/lane", time_it([&](int b) { setk(b); hipLaunchKernelGGL((k_loadonly<G, RPL, 1>), dim3((unsigned)((A * G + 255) / 256)), dim3(256), 0, 0, k); }, ITERS, RING)); \
     report("loadonly G=" #G " no ego", time_it([&](int b) { setk(b); hipLaunchKernelGGL((k_loadonly<G, RPL, 2>), dim3((unsigned)((A * G + 255) / 256)), dim3(256), 0, 0, k); }, ITERS, RING)); \
     report("loadonly G=" #G " 1 store/wave", time_it([&](int b) { setk(b); hipLaunchKernelGGL((k_loadonly<G, RPL, 3>), dim3((unsigned)((A * G + 255) / 256)), dim3(256), 0, 0, k); }, ITERS, RING)); \
