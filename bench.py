@@ -102,16 +102,58 @@ def slsqp_proxy(orc, p, w, n_qp=192, budget=6.0):
             "sample": "%d QPs, %.1f s" % (done, dt)}
 
 
+def large_batch(flt, device, agents=1 << 20, n=3, reps=60):
+    """The same kernel on 2^20 agents per launch (not part of `value`): at that size a launch is
+    no longer dominated by its start-up and tail.  The ring re-uses one C4 batch rotated by whole
+    tiles: 3 x 575 MB, more than twice the Infinity Cache."""
+    w = scenarios.config4(A=agents, seed=99)
+    ring = []
+    for b in range(n):
+        sh = 64 * 1237 * (b + 1)
+        ring.append(dict(
+            state=torch.from_numpy(np.roll(w["state"], sh, axis=0)).float().to(device),
+            u_ref=torch.from_numpy(np.roll(w["u_ref"], sh, axis=0)).float().to(device),
+            obs=planes_to_tiled(torch.from_numpy(np.roll(w["obs"], sh, axis=2)).float().to(device)),
+            u_out=torch.empty((agents, 2), dtype=torch.float32, device=device),
+            status=torch.empty((agents,), dtype=torch.int32, device=device)))
+    ty = torch.from_numpy(w["obs_type"]).to(device)
+    st = torch.cuda.Stream(device)
+    with torch.cuda.stream(st):
+        def walk():
+            for b in ring:
+                flt.solve(b["state"], b["u_ref"], b["obs"], ty, u_out=b["u_out"], status=b["status"])
+        walk()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=st):
+            walk()
+        for _ in range(reps):   # the GPU idled while the host built the batch: let the clocks come back
+            g.replay()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        for _ in range(reps):
+            g.replay()
+        e1.record(st)
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / (reps * n)
+    ab = algorithmic_bytes(agents, ROWS)
+    return {"agents": agents, "kernel_ms": ms, "solves_per_s": agents / (ms * 1e-3),
+            "achieved_GBps": ab / (ms * 1e-3) / 1e9, "frac": ab / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+            "launches": reps * n}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=20000)
+    ap.add_argument("--warmup", type=int, default=5000)
     ap.add_argument("--lanes", type=int, default=0, help="lanes per QP (0 = library default)")
     ap.add_argument("--agents", type=int, default=AGENTS)
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
     ap.add_argument("--planes", action="store_true", help="obstacles as (M,2,A,4) planes instead of 64-agent tiles")
+    ap.add_argument("--no-large", action="store_true", help="skip the extra 1M-agent measurement (N=1 only)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -236,6 +278,13 @@ def main():
         }
         if gather_ms is not None:
             out["gather_ms_per_step"] = gather_ms   # not part of value / ms_per_step
+        if world == 1 and not args.no_large and A == AGENTS:
+            try:
+                del ring
+                torch.cuda.empty_cache()
+                out["roofline_large_batch"] = large_batch(flt, device)
+            except Exception as e:  # extra information only
+                out["roofline_large_batch"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
