@@ -590,8 +590,9 @@ template <typename T, int RPL> struct LaneLoads {
 // re-read slot M-1 and are turned into empty rows afterwards.
 // NT: obstacle slots are loaded with the non-temporal hint (read once, not worth keeping in
 // L2 / Infinity Cache); pays off for batches much larger than those caches.
-template <typename T, int G, int RPL, bool QP_ONLY, bool NT>
-__device__ inline void group_load_(const KArgs<T>& p, long long qp, int g, LaneLoads<T, RPL>& L)
+// The lane's slots are m0, m0 + dm, ..., m0 + (RPL - 1) dm.
+template <typename T, int RPL, bool QP_ONLY, bool NT>
+__device__ inline void group_load_(const KArgs<T>& p, long long qp, int m0, int dm, LaneLoads<T, RPL>& L)
 {
     using v4 = typename VT<T>::v4;
     using v2 = typename VT<T>::v2;
@@ -606,7 +607,7 @@ __device__ inline void group_load_(const KArgs<T>& p, long long qp, int g, LaneL
     const unsigned long long toff = type_pa ? (unsigned long long)qp : 0ull;
 #pragma unroll
     for (int r = 0; r < RPL; ++r) {
-        const int m = r * G + g;
+        const int m = m0 + r * dm;
         const int mm = m < M ? m : M - 1;
         L.ty[r] = 0;
         // keep the issue order (the vmcnt counter retires loads in order, so the order
@@ -630,23 +631,21 @@ __device__ inline void group_load_(const KArgs<T>& p, long long qp, int g, LaneL
     __builtin_amdgcn_sched_barrier(0);
 }
 
-// Rows of this lane from its loaded slots, then the active-set iteration of the group.
-template <typename T, int G, int RPL, bool QP_ONLY>
-__device__ inline void group_solve_(const KArgs<T>& p, long long qp, int g, const LaneLoads<T, RPL>& L)
+// Rows of this lane (slots m0, m0 + dm, ...) from its loaded slots: unit normals in w-space.
+// Returns non-zero if the state, the nominal input or a row is not finite.
+template <typename T, int RPL, bool QP_ONLY>
+__device__ inline int lane_rows_(const KArgs<T>& p, long long qp, int m0, int dm, bool live,
+                                 const LaneLoads<T, RPL>& L, Ego<T>& e, T& ur0, T& ur1,
+                                 T (&at0)[RPL], T (&at1)[RPL], T (&bt)[RPL])
 {
     using v4 = typename VT<T>::v4;
     const int M = p.M;
-    Ego<T> e;
-    T ur0, ur1;
     int bad;
     make_ego_(p, L.sv, L.urv, QP_ONLY, e, ur0, ur1, bad);
-
-    // rows of this lane, unit normals in w-space
-    T at0[RPL], at1[RPL], bt[RPL];
     T chk = T(0);  // stays 0 while every row is finite (x * 0 is NaN for Inf / NaN)
 #pragma unroll
     for (int r = 0; r < RPL; ++r) {
-        const int m = r * G + g;
+        const int m = m0 + r * dm;
         T a0, a1, b, h;
         if (QP_ONLY) {
             a0 = L.oa[r].x; a1 = L.oa[r].y; b = L.oa[r].z; h = T(0);
@@ -655,35 +654,22 @@ __device__ inline void group_solve_(const KArgs<T>& p, long long qp, int g, cons
             const T o[8] = {L.oa[r].x, L.oa[r].y, L.oa[r].z, L.oa[r].w,
                             L.ob[r].x, L.ob[r].y, L.ob[r].z, L.ob[r].w};
             slot_row_(m < M ? L.ty[r] : SCCBF_OBS_EMPTY, o, e, p, a0, a1, b, h);
-            if (p.rows_out && m < M)
+            if (p.rows_out && m < M && live)
                 reinterpret_cast<v4*>(p.rows_out)[(long long)m * p.A + qp] = v4{a0, a1, b, h};
         }
         chk += a0 * T(0) + a1 * T(0) + b * T(0);
         to_wspace_(a0, a1, b, e, p, at0[r], at1[r], bt[r]);
     }
-    bad |= !(chk == T(0));
-    bad = (int)group_or<G>((unsigned)bad);
+    return bad | !(chk == T(0));
+}
 
-    // The rows also go to LDS, row m of the group's QP at [component][qp slot][m], so that
-    // the winning row of a step is one indexed read per component instead of a chain of
-    // selects over the registers of every lane.  Each wavefront reads only what it wrote.
-    constexpr int kMpad = G * RPL + 1;          // odd stride between QPs: fewer bank conflicts
-    constexpr int kPlane = (kBlock / G) * kMpad;
-    constexpr bool kLdsPick = (size_t)3 * kPlane * sizeof(T) <= 53 * 1024;  // 3 workgroups per CU at most
-    __shared__ T s_rows[kLdsPick ? 3 * kPlane : 1];
-    const int qslot = (int)(threadIdx.x / G) * kMpad;
-    if (kLdsPick) {
-#pragma unroll
-        for (int r = 0; r < RPL; ++r) {
-            s_rows[qslot + r * G + g] = at0[r];
-            s_rows[kPlane + qslot + r * G + g] = at1[r];
-            s_rows[2 * kPlane + qslot + r * G + g] = bt[r];
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-    }
-
-    // active-set iteration: take the most violated row, move the optimum onto it
+// Active-set iteration of a group of G lanes: lane g holds rows r G + g in registers; with
+// LDS_PICK all rows of the group's QP are also in LDS at s_rows[c * plane + qslot + m].
+template <typename T, int G, int RPL, bool LDS_PICK>
+__device__ inline Pivot<T> active_set_(int M, int g, const T (&at0)[RPL], const T (&at1)[RPL],
+                                       const T (&bt)[RPL], const T* s_rows, int plane, int qslot, int bad)
+{
+    // take the most violated row, move the optimum onto it
     Pivot<T> s;
     s.reset(bad ? SCCBF_STATUS_NONFINITE : SCCBF_STATUS_OPTIMAL);
     unsigned idx[RPL];  // 255 - row index: ties in violation go to the lowest index
@@ -714,11 +700,11 @@ __device__ inline void group_solve_(const KArgs<T>& p, long long qp, int g, cons
             return false;
         }
         T c0 = T(0), c1 = T(0), cb = T(0);
-        if (kLdsPick) {
+        if (LDS_PICK) {
             const int at = qslot + 255 - (kmax & 0xFF);
             c0 = s_rows[at];
-            c1 = s_rows[kPlane + at];
-            cb = s_rows[2 * kPlane + at];
+            c1 = s_rows[plane + at];
+            cb = s_rows[2 * plane + at];
         } else {
             // the lane that holds the winning row publishes it (the other lanes contribute 0)
 #pragma unroll
@@ -742,9 +728,39 @@ __device__ inline void group_solve_(const KArgs<T>& p, long long qp, int g, cons
     if (step(std::integral_constant<int, 0>(), true, 0) && step(std::integral_constant<int, 1>(), false, 1)) {
         for (int it = 2; step(std::integral_constant<int, 2>(), false, it); ++it) {}
     }
-    const int st = s.st;
-    const T w0 = s.w0, w1 = s.w1;
-    if (g == 0) store_result_(p, qp, QP_ONLY, st, w0, w1, e, ur0, ur1);
+    return s;
+}
+
+// Rows of this lane from its loaded slots, then the active-set iteration of the group.
+template <typename T, int G, int RPL, bool QP_ONLY>
+__device__ inline void group_solve_(const KArgs<T>& p, long long qp, int g, const LaneLoads<T, RPL>& L)
+{
+    Ego<T> e;
+    T ur0, ur1;
+    T at0[RPL], at1[RPL], bt[RPL];
+    int bad = lane_rows_<T, RPL, QP_ONLY>(p, qp, g, G, true, L, e, ur0, ur1, at0, at1, bt);
+    bad = (int)group_or<G>((unsigned)bad);
+
+    // The rows also go to LDS, row m of the group's QP at [component][qp slot][m], so that
+    // the winning row of a step is one indexed read per component instead of a chain of
+    // selects over the registers of every lane.  Each wavefront reads only what it wrote.
+    constexpr int kMpad = G * RPL + 1;          // odd stride between QPs: fewer bank conflicts
+    constexpr int kPlane = (kBlock / G) * kMpad;
+    constexpr bool kLdsPick = (size_t)3 * kPlane * sizeof(T) <= 53 * 1024;  // 3 workgroups per CU at most
+    __shared__ T s_rows[kLdsPick ? 3 * kPlane : 1];
+    const int qslot = (int)(threadIdx.x / G) * kMpad;
+    if (kLdsPick) {
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) {
+            s_rows[qslot + r * G + g] = at0[r];
+            s_rows[kPlane + qslot + r * G + g] = at1[r];
+            s_rows[2 * kPlane + qslot + r * G + g] = bt[r];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    const Pivot<T> s = active_set_<T, G, RPL, kLdsPick>(p.M, g, at0, at1, bt, s_rows, kPlane, qslot, bad);
+    if (g == 0) store_result_(p, qp, QP_ONLY, s.st, s.w0, s.w1, e, ur0, ur1);
 }
 
 // The arguments every wave needs before it can issue its first loads come first and one
@@ -761,7 +777,7 @@ __global__ __launch_bounds__(kBlock) void k_group(long long A, const T* obs, con
     const long long qp = (long long)blockIdx.x * (kBlock / G) + threadIdx.x / G;
     if (qp >= p.A) return;  // groups are lane-aligned: a whole group leaves together
     LaneLoads<T, RPL> L;
-    group_load_<T, G, RPL, QP_ONLY, NT>(p, qp, g, L);
+    group_load_<T, RPL, QP_ONLY, NT>(p, qp, g, G, L);
     group_solve_<T, G, RPL, QP_ONLY>(p, qp, g, L);
 }
 
