@@ -381,3 +381,43 @@ def test_fp32_vs_fp64_tolerance_sweep(oracle, alpha):
     du = np.abs(u32 - u64).max(axis=1)[both]
     print("alpha %.1f: max|du| %.3e  p99.9 %.3e  status agreement %.5f" % (
         alpha, du.max(), np.quantile(du, 0.999), (s32 == s64).mean()))
+
+
+@pytest.mark.parametrize("layout", ["planes", "tiles"])
+def test_batch_beyond_4_gib_of_obstacles(oracle, layout):
+    """9 M agents x 16 slots (fp32): the obstacle array is 4.6 GB, so slot offsets exceed 32 bits.
+    Inputs are made on the device; the oracle checks agents sampled over the whole range,
+    the last ones included."""
+    from sccav_cbf_amd.batched import planes_to_tiled
+    A, M = 9_000_000, 16
+    g = torch.Generator(device=_dev()).manual_seed(7)
+
+    def U(shape, lo, hi):
+        return torch.rand(shape, generator=g, device=_dev(), dtype=torch.float32) * (hi - lo) + lo
+
+    state = torch.stack([U((A,), -50, 50), U((A,), -50, 50), U((A,), -3.1, 3.1), U((A,), 0, 15)], dim=1).contiguous()
+    u_ref = torch.stack([U((A,), -2, 2), U((A,), -0.4, 0.4)], dim=1).contiguous()
+    obs = torch.zeros((M, 2, A, 4), dtype=torch.float32, device=_dev())
+    for m in range(M):
+        rng_, brg = U((A,), 15, 60), U((A,), -3.1, 3.1)
+        obs[m, 0, :, 0] = state[:, 0] + rng_ * torch.cos(brg)
+        obs[m, 0, :, 1] = state[:, 1] + rng_ * torch.sin(brg)
+        if m < 8:      # ellipse: cx, cy, a, b | theta, vx, vy
+            obs[m, 0, :, 2], obs[m, 0, :, 3] = U((A,), 2, 20), U((A,), 1, 10)
+            obs[m, 1, :, 0], obs[m, 1, :, 1], obs[m, 1, :, 2] = U((A,), -3.1, 3.1), U((A,), -2, 2), U((A,), -2, 2)
+        else:          # cone: cx, cy, theta_o, v_o | a, beta
+            obs[m, 0, :, 2], obs[m, 0, :, 3] = U((A,), -3.1, 3.1), U((A,), 0, 5)
+            obs[m, 1, :, 0] = U((A,), 2.5, 6.5)
+    ty = torch.tensor([0] * 8 + [1] * 8, dtype=torch.uint8, device=_dev())
+    idx = torch.cat([torch.randint(0, A, (2000,), generator=g, device=_dev()),
+                     torch.arange(A - 70, A, device=_dev()), torch.arange(0, 70, device=_dev())])
+    w = dict(state=state[idx].double().cpu().numpy(), u_ref=u_ref[idx].double().cpu().numpy(),
+             obs=np.ascontiguousarray(obs[:, :, idx, :].double().cpu().numpy()), obs_type=ty.cpu().numpy())
+    if layout == "tiles":
+        obs = planes_to_tiled(obs)
+    f = _filter(slip_io=True)
+    u, st = f.solve(state, u_ref, obs, ty)
+    torch.cuda.synchronize()
+    del obs
+    uo, so, ro = _orc_solve(oracle, w)
+    _check(u[idx].double().cpu().numpy(), st[idx].cpu().numpy(), uo, so, ro, w["u_ref"], torch.float32)
