@@ -222,6 +222,53 @@ int sccbf_vehicle_step_f32(int64_t A, float* state, const float* u, double lr, d
 int sccbf_vehicle_step_f64(int64_t A, double* state, const double* u, double lr, double lf,
                            double max_steer, double dt, double* beta_out, void* stream);
 
+/*
+ * Closed-loop rollout: `ticks` control ticks of
+ *     nominal input (sccbf_nominal_*) -> filter (sccbf_solve_*, DBM) -> vehicle step
+ *     (sccbf_vehicle_step_*) -> obstacle motion
+ * for every agent in one launch; the main loop of the reference drivers
+ * (test_scripts/stanley_controller_ellipse.py:630-760) for a whole batch.  Tick by tick
+ * the results are those of the three entry points called in turn.
+ */
+#define SCCBF_MOTION_STATIC 0            /* obstacle slots stay where they are */
+#define SCCBF_MOTION_CONSTANT_VELOCITY 1 /* per tick: ellipse centre += (vx, vy) dt; cone centre
+                                            += v_o (cos, sin)(theta_o + beta) dt; radial centre
+                                            += (cdot_x, cdot_y) dt; lanes stay */
+typedef struct sccbf_rollout_params {
+    double max_steer; /* steering clip of the vehicle step [rad] */
+    double dt;        /* tick length [s] */
+    int32_t ticks;
+    int32_t motion;   /* SCCBF_MOTION_* */
+} sccbf_rollout_params;
+
+/* max_steer 30 deg, dt 0.1 (stanley_controller_ellipse.py:54,58), 0 ticks, static obstacles */
+void sccbf_default_rollout_params(sccbf_rollout_params* p);
+
+/*
+ *   state        T[A][4]   in: initial states; out: states after the last tick
+ *   traj         T[N][4]   course, 1 <= N <= 2048 way-points (SCCBF_ERR_ROWS beyond)
+ *   target_idx   i32[A]    in/out, as in sccbf_nominal_*
+ *   pid_state    T[A][2]   in/out or NULL, as in sccbf_nominal_*
+ *   obs, obs_type          as in sccbf_solve_* (planes or tiles; not the shared table), 1 <= M <= 64;
+ *                          read once: moving obstacles advance in registers, obs is not written
+ *   h_min        T[A]      optional: least barrier value over all ticks and slots
+ *   n_active     i32[A]    optional: ticks on which the filter changed the nominal input
+ *   n_infeasible i32[A]    optional: ticks with SCCBF_STATUS_INFEASIBLE
+ *   trace        T[ticks][A][4] optional: per tick a*, delta*, slip angle beta of the step, status
+ */
+int sccbf_rollout_f32(const sccbf_params* p, const sccbf_nominal_params* np,
+                      const sccbf_rollout_params* rp, int64_t A, int32_t M, int32_t N,
+                      float* state, const float* traj, int32_t* target_idx, float* pid_state,
+                      const float* obs, const uint8_t* obs_type,
+                      float* h_min, int32_t* n_active, int32_t* n_infeasible, float* trace,
+                      void* stream);
+int sccbf_rollout_f64(const sccbf_params* p, const sccbf_nominal_params* np,
+                      const sccbf_rollout_params* rp, int64_t A, int32_t M, int32_t N,
+                      double* state, const double* traj, int32_t* target_idx, double* pid_state,
+                      const double* obs, const uint8_t* obs_type,
+                      double* h_min, int32_t* n_active, int32_t* n_infeasible, double* trace,
+                      void* stream);
+
 #ifdef __cplusplus
 }
 #endif

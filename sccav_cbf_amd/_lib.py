@@ -17,7 +17,9 @@ ERR_ARG, ERR_ROWS, ERR_WEIGHT, ERR_LAUNCH, ERR_VARIANT, ERR_NO_DEVICE = -1, -2, 
 EXPORTS = ("sccbf_version", "sccbf_strerror", "sccbf_default_params", "sccbf_solve_f32",
            "sccbf_solve_f64", "sccbf_qp_f32", "sccbf_qp_f64", "sccbf_partials_f32",
            "sccbf_partials_f64", "sccbf_default_nominal_params", "sccbf_nominal_f32",
-           "sccbf_nominal_f64", "sccbf_vehicle_step_f32", "sccbf_vehicle_step_f64")
+           "sccbf_nominal_f64", "sccbf_vehicle_step_f32", "sccbf_vehicle_step_f64",
+           "sccbf_default_rollout_params", "sccbf_rollout_f32", "sccbf_rollout_f64")
+MOTION_STATIC, MOTION_CONSTANT_VELOCITY = 0, 1
 NOMINAL_WAYPOINT_SPEED = 1
 
 
@@ -33,6 +35,11 @@ class NominalParams(C.Structure):
     _fields_ = [("axle", C.c_double), ("k", C.c_double), ("ks", C.c_double), ("kp", C.c_double),
                 ("ki", C.c_double), ("kd", C.c_double), ("dt", C.c_double), ("target_speed", C.c_double),
                 ("flags", C.c_uint32), ("reserved", C.c_int32)]
+
+
+class RolloutParams(C.Structure):
+    """struct sccbf_rollout_params of include/sccbf.h."""
+    _fields_ = [("max_steer", C.c_double), ("dt", C.c_double), ("ticks", C.c_int32), ("motion", C.c_int32)]
 
 
 class SccbfError(RuntimeError):
@@ -80,6 +87,13 @@ def load():
         f = getattr(L, name)
         f.restype = C.c_int
         f.argtypes = [C.c_int64, vp, vp, C.c_double, C.c_double, C.c_double, C.c_double, vp, vp]
+    L.sccbf_default_rollout_params.restype = None
+    L.sccbf_default_rollout_params.argtypes = [C.POINTER(RolloutParams)]
+    for name in ("sccbf_rollout_f32", "sccbf_rollout_f64"):
+        f = getattr(L, name)
+        f.restype = C.c_int
+        f.argtypes = [C.POINTER(Params), C.POINTER(NominalParams), C.POINTER(RolloutParams), C.c_int64,
+                      C.c_int32, C.c_int32] + [vp] * 11
     _lib = L
     return L
 

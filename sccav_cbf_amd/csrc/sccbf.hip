@@ -38,6 +38,9 @@ constexpr int kBlock = SCCBF_BLOCK;
 #define SCCBF_TILE 64  // agents per tile of the tiled obstacle layout
 #endif
 constexpr int kTile = SCCBF_TILE;
+#ifndef SCCBF_ROLLOUT_WAVES
+#define SCCBF_ROLLOUT_WAVES 4
+#endif
 constexpr int kLaneIters = 32;     // Newton iterations for the lane closest point
 constexpr int kLaneHalvings = 30;  // step halvings per iteration
 
@@ -550,9 +553,10 @@ __device__ inline void load_ego_(const KArgs<T>& p, long long qp, bool qp_only, 
     make_ego_(p, s, ur, qp_only, e, ur0, ur1, bad);
 }
 
+// The filter's answer in the caller's coordinates from the optimum w of the QP.
 template <typename T>
-__device__ inline void store_result_(const KArgs<T>& p, long long qp, bool qp_only, int st,
-                                     T w0, T w1, const Ego<T>& e, T ur0, T ur1)
+__device__ inline typename VT<T>::v2 result_u_(const KArgs<T>& p, bool qp_only, int st, T w0, T w1,
+                                               const Ego<T>& e, T ur0, T ur1)
 {
     using v2 = typename VT<T>::v2;
     v2 out;
@@ -572,7 +576,15 @@ __device__ inline void store_result_(const KArgs<T>& p, long long qp, bool qp_on
         else
             out.y = atan_(tan_(u1) * p.k_out);  // atan2((lf + lr) tan(beta), lr), lr > 0: reference cbf/cbf.py:216
     }
-    reinterpret_cast<v2*>(p.u_out)[qp] = out;
+    return out;
+}
+
+template <typename T>
+__device__ inline void store_result_(const KArgs<T>& p, long long qp, bool qp_only, int st,
+                                     T w0, T w1, const Ego<T>& e, T ur0, T ur1)
+{
+    using v2 = typename VT<T>::v2;
+    reinterpret_cast<v2*>(p.u_out)[qp] = result_u_(p, qp_only, st, w0, w1, e, ur0, ur1);
     p.status[qp] = st;
 }
 
@@ -636,7 +648,7 @@ __device__ inline void group_load_(const KArgs<T>& p, long long qp, int m0, int 
 template <typename T, int RPL, bool QP_ONLY>
 __device__ inline int lane_rows_(const KArgs<T>& p, long long qp, int m0, int dm, bool live,
                                  const LaneLoads<T, RPL>& L, Ego<T>& e, T& ur0, T& ur1,
-                                 T (&at0)[RPL], T (&at1)[RPL], T (&bt)[RPL])
+                                 T (&at0)[RPL], T (&at1)[RPL], T (&bt)[RPL], T* h_min = nullptr)
 {
     using v4 = typename VT<T>::v4;
     const int M = p.M;
@@ -653,9 +665,11 @@ __device__ inline int lane_rows_(const KArgs<T>& p, long long qp, int m0, int dm
         } else {
             const T o[8] = {L.oa[r].x, L.oa[r].y, L.oa[r].z, L.oa[r].w,
                             L.ob[r].x, L.ob[r].y, L.ob[r].z, L.ob[r].w};
-            slot_row_(m < M ? L.ty[r] : SCCBF_OBS_EMPTY, o, e, p, a0, a1, b, h);
+            const int ty = m < M ? L.ty[r] : SCCBF_OBS_EMPTY;
+            slot_row_(ty, o, e, p, a0, a1, b, h);
             if (p.rows_out && m < M && live)
                 reinterpret_cast<v4*>(p.rows_out)[(long long)m * p.A + qp] = v4{a0, a1, b, h};
+            if (h_min && ty >= 0 && ty <= SCCBF_OBS_RADIAL) *h_min = min_(*h_min, h);  // real slots only
         }
         chk += a0 * T(0) + a1 * T(0) + b * T(0);
         to_wspace_(a0, a1, b, e, p, at0[r], at1[r], bt[r]);
@@ -926,8 +940,9 @@ template <typename T> struct NArgs {
 constexpr int kTrajChunk = 2048;  // way-points staged in LDS per pass
 constexpr int kSub = 32;          // way-points per bounding box
 constexpr int kSubs = kTrajChunk / kSub;
-constexpr int kNomBlock = 1024;   // threads per workgroup of the nominal kernel: 256 agents share one staging
-static_assert(kNomBlock * 2 == kTrajChunk && kSub == 16 * 2, "staging below: 2 points per thread, 16 threads per box");
+constexpr int kSubStride = kSub + 1;  // odd stride: groups scanning different runs hit different banks
+constexpr int kNomLanes = 4;          // lanes per agent in the nominal and rollout kernels
+constexpr int kNomBlock = 1024;       // threads per workgroup of the nominal kernel: 256 agents share one staging
 
 template <typename T> __device__ inline T wrap_pi_(T a)
 {
@@ -939,37 +954,140 @@ template <typename T> __device__ inline T wrap_pi_(T a)
     return a;
 }
 
-template <typename T> __device__ inline T row16_min_(T v)  // over 16 consecutive lanes
+// One pass (up to 2048 way-points) of the course in LDS: coordinates in runs of 32 and the
+// bounding box of every run (four extra empty boxes for the four-at-a-time walk).
+template <typename T> struct CoursePass {
+    T x[kSubs * kSubStride], y[kSubs * kSubStride];
+    T x0[kSubs + kNomLanes], x1[kSubs + kNomLanes], y0[kSubs + kNomLanes], y1[kSubs + kNomLanes];
+};
+
+// Every thread of a BLOCK-thread workgroup takes 2048 / BLOCK consecutive way-points of the
+// pass [base, base + n); 32 * BLOCK / 2048 neighbouring threads make one run and reduce its
+// box by shuffles.  Way-points past the end are infinitely far, runs past the end empty.
+// The caller puts a workgroup barrier before and after.
+template <typename T, int BLOCK>
+__device__ inline void stage_course_(CoursePass<T>& c, const typename VT<T>::v4* traj4, int base, int n)
 {
+    using v2 = typename VT<T>::v2;
+    constexpr int kPer = kTrajChunk / BLOCK;  // way-points per thread
+    constexpr int kThr = kSub / kPer;         // threads per run
+    static_assert(kPer * BLOCK == kTrajChunk && kThr * kPer == kSub && kThr <= 64, "block size");
+    T x0 = INFINITY, x1 = -INFINITY, y0 = INFINITY, y1 = -INFINITY;
+    const int r = threadIdx.x / kThr, j0 = (threadIdx.x % kThr) * kPer;
 #pragma unroll
-    for (int m = 1; m < 16; m *= 2) v = min_(v, __shfl_xor(v, m, 64));
-    return v;
+    for (int j = 0; j < kPer; ++j) {
+        const int i = threadIdx.x * kPer + j;
+        T x = INFINITY, y = INFINITY;
+        if (i < n) {
+            const v2 w = *reinterpret_cast<const v2*>(traj4 + base + i);
+            x = w.x; y = w.y;
+            x0 = min_(x0, x); x1 = max_(x1, x);
+            y0 = min_(y0, y); y1 = max_(y1, y);
+        }
+        c.x[r * kSubStride + j0 + j] = x;
+        c.y[r * kSubStride + j0 + j] = y;
+    }
+#pragma unroll
+    for (int m = 1; m < kThr; m *= 2) {
+        x0 = min_(x0, __shfl_xor(x0, m, 64)); x1 = max_(x1, __shfl_xor(x1, m, 64));
+        y0 = min_(y0, __shfl_xor(y0, m, 64)); y1 = max_(y1, __shfl_xor(y1, m, 64));
+    }
+    if (threadIdx.x % kThr == 0) {
+        c.x0[r] = x0; c.x1[r] = x1; c.y0[r] = y0; c.y1[r] = y1;
+    }
+    if (threadIdx.x < kNomLanes) {
+        c.x0[kSubs + threadIdx.x] = INFINITY; c.x1[kSubs + threadIdx.x] = -INFINITY;
+        c.y0[kSubs + threadIdx.x] = INFINITY; c.y1[kSubs + threadIdx.x] = -INFINITY;
+    }
 }
-template <typename T> __device__ inline T row16_max_(T v)
+
+// Nearest way-point of one staged pass to (fx, fy), by the four lanes of a group: they step
+// through the boxes four at a time and scan (eight way-points each) only the runs whose box
+// is not farther than lim, the best squared distance known so far (on entry: any upper bound
+// of the answer).  best / bi: this lane's nearest way-point so far (strict "<" in index
+// order, so the first index wins a tie).  Every group walks its own list of runs: a wavefront
+// pays for the longest list among its groups, not for their union.
+template <typename T>
+__device__ inline void nearest_in_pass_(const CoursePass<T>& c, T fx, T fy, int g, int base, int runs,
+                                        T& lim, T& best, int& bi)
 {
+    constexpr int G = kNomLanes;
+    for (int r = 0; r < runs;) {  // r and lim are the same in the four lanes of a group
+        // lane g looks at the box of run r + g (infinitely far when the run is empty)
+        const T dx = max_(max_(c.x0[r + g] - fx, fx - c.x1[r + g]), T(0));
+        const T dy = max_(max_(c.y0[r + g] - fy, fy - c.y1[r + g]), T(0));
+        // (a few ulps of slack: the box distance and the way-point distance round independently)
+        const unsigned hit = group_or<G>((dx * dx + dy * dy <= lim * (T(1) + T(8) * Lim<T>::eps)) ? 1u << g : 0u);
+        if (hit == 0u) {
+            r += G;
+            continue;
+        }
+        r += __ffs(hit) - 1;  // the first run of the four that can hold the answer
 #pragma unroll
-    for (int m = 1; m < 16; m *= 2) v = max_(v, __shfl_xor(v, m, 64));
-    return v;
+        for (int j = 0; j < kSub / G; ++j) {  // lane g: way-points 8 g .. 8 g + 7 of the run
+            const int jj = g * (kSub / G) + j;
+            const T ex = fx - c.x[r * kSubStride + jj], ey = fy - c.y[r * kSubStride + jj];
+            const T d = ex * ex + ey * ey;
+            const bool lt = d < best;
+            best = lt ? d : best;
+            bi = lt ? base + r * kSub + jj : bi;
+        }
+        // tighten the bound with the group's best so far
+        T m = best;
+        m = min_(m, __shfl_xor(m, 1, 64));
+        m = min_(m, __shfl_xor(m, 2, 64));
+        lim = min_(lim, m);
+        ++r;
+    }
+}
+
+// the group's answer: least distance, then least index
+template <typename T> __device__ inline int group_nearest_(T best, int bi, int N)
+{
+    T m = best;
+    m = min_(m, __shfl_xor(m, 1, 64));
+    m = min_(m, __shfl_xor(m, 2, 64));
+    int c = best == m ? bi : 0x7fffffff;
+    c = min(c, __shfl_xor(c, 1, 64));
+    c = min(c, __shfl_xor(c, 2, 64));
+    return min(c, N - 1);  // (non-finite state: no way-point compares nearer; any index will do)
+}
+
+// Stanley steering and PID speed control from the nearest way-point (xn, yn), the target
+// way-point's (yaw, v_des) and the PID state ps = (previous error, integral), updated in place.
+// Reference cbf/controllers.py:96-99, 118-119, 141-147, 173-180.
+template <typename T>
+__device__ inline void stanley_pid_(const NArgs<T>& p, T yaw, T v, T sth, T cth, T fx, T fy, T xn, T yn,
+                                    T yaw_des, T v_des, bool pid, typename VT<T>::v2& ps, T& acc, T& delta)
+{
+    // cross-track error projected on the axle direction (-cos(yaw + pi/2), -sin(yaw + pi/2)) = (sin yaw, -cos yaw)
+    const T err = (fx - xn) * sth - (fy - yn) * cth;
+    const T theta_e = wrap_pi_(yaw_des - yaw);
+    const T theta_d = atan2_(p.k * err, v + p.ks);
+    delta = theta_e + theta_d;
+    const T vt = (p.flags & SCCBF_NOMINAL_WAYPOINT_SPEED) ? v_des : p.target_speed;
+    const T e = vt - v;
+    acc = p.kp * e;
+    if (pid) {
+        const T de = (e - ps.x) * p.inv_dt;
+        ps.y += p.dt * e;
+        acc = p.kp * e + p.ki * ps.y + p.kd * de;
+        ps.x = e;
+    }
 }
 
 // Four lanes per agent.  The nearest way-point is searched over the whole course
 // (controllers.py:89-93: np.argmin of np.hypot, first index on ties; squared distances order
 // the same way), exactly but not exhaustively: the workgroup stages the course through LDS
-// 2048 way-points at a time together with the bounding box of every run of 32.  The distance
-// to last tick's target way-point bounds the answer from above; the four lanes step through
-// the boxes four at a time and scan (eight way-points each) only the runs whose box is not
-// farther than the best distance known so far.  Every group walks its own list of runs, so a
-// wavefront pays for the longest list among its groups, not for their union.
-constexpr int kNomLanes = 4;
+// 2048 way-points at a time together with the bounding box of every run of 32, and the
+// distance to last tick's target way-point bounds the answer from above (nearest_in_pass_).
 template <typename T>
 __global__ __launch_bounds__(kNomBlock) void k_nominal(const NArgs<T> p)
 {
     using v4 = typename VT<T>::v4;
     using v2 = typename VT<T>::v2;
     constexpr int G = kNomLanes;
-    constexpr int kStride = kSub + 1;  // odd stride: groups scanning different runs hit different banks
-    __shared__ T s_x[kSubs * kStride], s_y[kSubs * kStride];
-    __shared__ T s_x0[kSubs + G], s_x1[kSubs + G], s_y0[kSubs + G], s_y1[kSubs + G];
+    __shared__ CoursePass<T> c;
     const int g = threadIdx.x % G;
     long long a = (long long)blockIdx.x * (kNomBlock / G) + threadIdx.x / G;
     const bool live = a < p.A;
@@ -986,105 +1104,49 @@ __global__ __launch_bounds__(kNomBlock) void k_nominal(const NArgs<T> p)
         const v2 wl = *reinterpret_cast<const v2*>(traj4 + min(max(last, 0), p.N - 1));
         lim = (fx - wl.x) * (fx - wl.x) + (fy - wl.y) * (fy - wl.y);
     }
-    T best = INFINITY;  // of this lane's way-points; strict "<" in index order: first index on ties
+    T best = INFINITY;
     int bi = 0x7fffffff;
-
-    if (threadIdx.x < G) {  // boxes past the last run (read by the four-at-a-time walk): empty
-        s_x0[kSubs + threadIdx.x] = INFINITY; s_x1[kSubs + threadIdx.x] = -INFINITY;
-        s_y0[kSubs + threadIdx.x] = INFINITY; s_y1[kSubs + threadIdx.x] = -INFINITY;
-    }
     for (int base = 0; base < p.N; base += kTrajChunk) {
         const int n = min(kTrajChunk, p.N - base);
         __syncthreads();
-        {   // stage: thread t takes way-points 2 t, 2 t + 1; sixteen threads make one run of 32
-            T x0 = INFINITY, x1 = -INFINITY, y0 = INFINITY, y1 = -INFINITY;
-            const int r = threadIdx.x / 16, j0 = (threadIdx.x % 16) * 2;
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int i = threadIdx.x * 2 + j;
-                T x = INFINITY, y = INFINITY;  // past the end: never the nearest
-                if (i < n) {
-                    const v2 w = *reinterpret_cast<const v2*>(traj4 + base + i);
-                    x = w.x; y = w.y;
-                    x0 = min_(x0, x); x1 = max_(x1, x);
-                    y0 = min_(y0, y); y1 = max_(y1, y);
-                }
-                s_x[r * kStride + j0 + j] = x;
-                s_y[r * kStride + j0 + j] = y;
-            }
-            x0 = row16_min_(x0); x1 = row16_max_(x1);
-            y0 = row16_min_(y0); y1 = row16_max_(y1);
-            if (threadIdx.x % 16 == 0) {
-                s_x0[r] = x0; s_x1[r] = x1; s_y0[r] = y0; s_y1[r] = y1;
-            }
-        }
+        stage_course_<T, kNomBlock>(c, traj4, base, n);
         __syncthreads();
-        const int runs = (n + kSub - 1) / kSub;
-        for (int r = 0; r < runs;) {  // r and lim are the same in the four lanes of a group
-            // lane g looks at the box of run r + g (infinitely far when the run is empty)
-            const T dx = max_(max_(s_x0[r + g] - fx, fx - s_x1[r + g]), T(0));
-            const T dy = max_(max_(s_y0[r + g] - fy, fy - s_y1[r + g]), T(0));
-            // (a few ulps of slack: the box distance and the way-point distance round independently)
-            const unsigned hit = group_or<G>((dx * dx + dy * dy <= lim * (T(1) + T(8) * Lim<T>::eps)) ? 1u << g : 0u);
-            if (hit == 0u) {
-                r += G;
-                continue;
-            }
-            r += __ffs(hit) - 1;  // the first run of the four that can hold the answer
-#pragma unroll
-            for (int j = 0; j < kSub / G; ++j) {  // lane g: way-points 8 g .. 8 g + 7 of the run
-                const int jj = g * (kSub / G) + j;
-                const T ex = fx - s_x[r * kStride + jj], ey = fy - s_y[r * kStride + jj];
-                const T d = ex * ex + ey * ey;
-                const bool lt = d < best;
-                best = lt ? d : best;
-                bi = lt ? base + r * kSub + jj : bi;
-            }
-            // tighten the bound with the group's best so far
-            T m = best;
-            m = min_(m, __shfl_xor(m, 1, 64));
-            m = min_(m, __shfl_xor(m, 2, 64));
-            lim = min_(lim, m);
-            ++r;
-        }
+        nearest_in_pass_(c, fx, fy, g, base, (n + kSub - 1) / kSub, lim, best, bi);
     }
-    {   // the group's answer: least distance, then least index
-        T m = best;
-        m = min_(m, __shfl_xor(m, 1, 64));
-        m = min_(m, __shfl_xor(m, 2, 64));
-        int c = best == m ? bi : 0x7fffffff;
-        c = min(c, __shfl_xor(c, 1, 64));
-        c = min(c, __shfl_xor(c, 2, 64));
-        bi = min(c, p.N - 1);  // (non-finite state: no way-point compares nearer; any index will do)
-    }
-    // cross-track error at the nearest way-point, projected on the axle direction
-    // (-cos(yaw + pi/2), -sin(yaw + pi/2)) = (sin yaw, -cos yaw): controllers.py:96-99
+    bi = group_nearest_(best, bi, p.N);
     const v4 wn = traj4[bi];
-    const T err = (fx - wn.x) * sth - (fy - wn.y) * cth;
     const int idx = last >= bi ? last : bi;  // controllers.py:118-119
     const v4 wt = traj4[min(idx, p.N - 1)];
-    const T theta_e = wrap_pi_(wt.z - s.z);
-    const T theta_d = atan2_(p.k * err, s.w + p.ks);
-    const T vt = (p.flags & SCCBF_NOMINAL_WAYPOINT_SPEED) ? wt.w : p.target_speed;
-    const T e = vt - s.w;
-    T acc = p.kp * e;
-    if (p.pid_state) {
-        v2 ps = reinterpret_cast<v2*>(p.pid_state)[a];
-        const T de = (e - ps.x) * p.inv_dt;
-        ps.y += p.dt * e;
-        acc = p.kp * e + p.ki * ps.y + p.kd * de;
-        ps.x = e;
-        if (live && g == 0) reinterpret_cast<v2*>(p.pid_state)[a] = ps;
-    }
+    v2 ps = v2{T(0), T(0)};
+    if (p.pid_state) ps = reinterpret_cast<v2*>(p.pid_state)[a];
+    T acc, delta;
+    stanley_pid_(p, s.z, s.w, sth, cth, fx, fy, wn.x, wn.y, wt.z, wt.w, p.pid_state != nullptr, ps, acc, delta);
     if (live && g == 0) {
+        if (p.pid_state) reinterpret_cast<v2*>(p.pid_state)[a] = ps;
         p.target_idx[a] = idx;
-        reinterpret_cast<v2*>(p.u_ref)[a] = v2{acc, theta_e + theta_d};
+        reinterpret_cast<v2*>(p.u_ref)[a] = v2{acc, delta};
     }
 }
 
 // ------------------------------------------------------- vehicle step (update_com)
+// State.update_com, reference test_scripts/stanley_controller_ellipse.py:122-131; returns beta.
 template <typename T>
-__global__ __launch_bounds__(kBlock) void k_vehicle_step(long long A, T* state, const T* u, T lr, T k_in,
+__device__ inline T vehicle_step_(typename VT<T>::v4& s, T acc, T delta_in, T k_in, T inv_lr, T max_steer, T dt)
+{
+    const T delta = min_(max_(delta_in, -max_steer), max_steer);
+    const T beta = atan_(tan_(delta) * k_in);  // atan2(lr tan(delta), lf + lr), lf + lr > 0
+    T sth, cth;
+    sincos_(s.z, &sth, &cth);
+    const T v = s.w;
+    s.x += (v * cth - v * sth * beta) * dt;
+    s.y += (v * sth + v * cth * beta) * dt;
+    s.z += (v * beta * inv_lr) * dt;
+    s.w += acc * dt;
+    return beta;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_vehicle_step(long long A, T* state, const T* u, T k_in,
                                                          T inv_lr, T max_steer, T dt, T* beta_out)
 {
     using v4 = typename VT<T>::v4;
@@ -1093,17 +1155,153 @@ __global__ __launch_bounds__(kBlock) void k_vehicle_step(long long A, T* state, 
     if (a >= A) return;
     v4 s = reinterpret_cast<v4*>(state)[a];
     const v2 in = reinterpret_cast<const v2*>(u)[a];
-    const T delta = min_(max_(in.y, -max_steer), max_steer);
-    const T beta = atan_(tan_(delta) * k_in);  // atan2(lr tan(delta), lf + lr), lf + lr > 0
-    T sth, cth;
-    sincos_(s.z, &sth, &cth);
-    const T v = s.w;
-    s.x += (v * cth - v * sth * beta) * dt;
-    s.y += (v * sth + v * cth * beta) * dt;
-    s.z += (v * beta * inv_lr) * dt;
-    s.w += in.x * dt;
+    const T beta = vehicle_step_<T>(s, in.x, in.y, k_in, inv_lr, max_steer, dt);
     reinterpret_cast<v4*>(state)[a] = s;
     if (beta_out) beta_out[a] = beta;
+}
+
+// ---------------------------------------------------- closed-loop rollout in one launch
+template <typename T> struct RArgs {
+    KArgs<T> f;   // filter: parameters, obs, obs_type, M, flags (state / u_ref / u_out / status unused)
+    NArgs<T> n;   // nominal: parameters, traj, N, target_idx (in/out), pid_state (in/out)
+    T* state;     // [A][4] in/out
+    T k_in, inv_lr, max_steer, dt;
+    int ticks;
+    int motion;   // SCCBF_MOTION_*
+    T* h_min;     // [A] optional
+    int* n_active;      // [A] optional
+    int* n_infeasible;  // [A] optional
+    T* trace;     // [ticks][A][4] optional
+};
+
+// obstacle slots move between ticks (constant velocity): ellipse by (vx, vy), collision cone by
+// v_o along theta_o + beta, radial by (cdot_x, cdot_y); lanes and empty slots stay
+template <typename T>
+__device__ inline void advance_slot_(int type, typename VT<T>::v4& oa, typename VT<T>::v4& ob, T dt)
+{
+    if (type == SCCBF_OBS_ELLIPSE) {
+        oa.x += ob.y * dt;
+        oa.y += ob.z * dt;
+    } else if (type == SCCBF_OBS_CONE) {
+        T so, co;
+        sincos_(oa.z + ob.y, &so, &co);
+        oa.x += oa.w * co * dt;
+        oa.y += oa.w * so * dt;
+    } else if (type == SCCBF_OBS_RADIAL) {
+        oa.x += ob.x * dt;
+        oa.y += ob.y * dt;
+    }
+}
+
+// `ticks` control ticks of nominal controller -> filter -> vehicle step (-> obstacle motion)
+// for every agent in ONE launch: four lanes per agent, the agent's state, its obstacle slots
+// (four per lane), target index and PID state stay in registers, the course (at most 2048
+// way-points) and its run boxes are staged in LDS once per workgroup, the rows of each tick go
+// through the per-wavefront LDS table of the 4-lane filter kernel.  No HBM traffic inside the
+// loop except the optional trace.
+template <typename T, int RPL>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SCCBF_ROLLOUT_WAVES, SCCBF_ROLLOUT_WAVES)))
+void k_rollout(const RArgs<T> a)
+{
+    using v4 = typename VT<T>::v4;
+    using v2 = typename VT<T>::v2;
+    constexpr int G = kNomLanes;
+    constexpr int kMpad = G * RPL + 1;
+    constexpr int kPlane = (kBlock / G) * kMpad;
+    __shared__ CoursePass<T> c;
+    __shared__ T s_yaw[kTrajChunk];
+    __shared__ T s_rows[3 * kPlane];
+    const KArgs<T>& p = a.f;
+    const NArgs<T>& np = a.n;
+    const int g = threadIdx.x % G;
+    long long ag = (long long)blockIdx.x * (kBlock / G) + threadIdx.x / G;
+    const bool live = ag < p.A;
+    if (!live) ag = p.A - 1;  // stays for the barrier; stores are masked
+    const int qslot = (int)(threadIdx.x / G) * kMpad;
+    const v4* traj4 = reinterpret_cast<const v4*>(np.traj);
+
+    stage_course_<T, kBlock>(c, traj4, 0, np.N);
+    for (int i = threadIdx.x; i < np.N; i += kBlock) s_yaw[i] = traj4[i].z;
+
+    // this lane's obstacle slots (r G + g) and everything the agent carries from tick to tick
+    LaneLoads<T, RPL> L;
+    {
+        KArgs<T> q = p;
+        q.state = a.state;
+        q.u_ref = np.u_ref;  // any readable (A, 2) array: overwritten below before use
+        group_load_<T, RPL, false, false>(q, ag, g, G, L);
+    }
+    v4 st = L.sv;
+    int tgt = np.target_idx[ag];
+    v2 ps = v2{T(0), T(0)};
+    if (np.pid_state) ps = reinterpret_cast<v2*>(np.pid_state)[ag];
+    T h_min = INFINITY;
+    int n_act = 0, n_inf = 0;
+    __syncthreads();
+    const int runs = (np.N + kSub - 1) / kSub;
+
+    for (int tick = 0; tick < a.ticks; ++tick) {
+        // nominal input
+        T sth, cth;
+        sincos_(st.z, &sth, &cth);
+        const T fx = st.x + np.axle * cth, fy = st.y + np.axle * sth;
+        const int lt = min(max(tgt, 0), np.N - 1);
+        const T lx = c.x[(lt / kSub) * kSubStride + lt % kSub], ly = c.y[(lt / kSub) * kSubStride + lt % kSub];
+        T lim = (fx - lx) * (fx - lx) + (fy - ly) * (fy - ly);
+        T best = INFINITY;
+        int bi = 0x7fffffff;
+        nearest_in_pass_(c, fx, fy, g, 0, runs, lim, best, bi);
+        bi = group_nearest_(best, bi, np.N);
+        tgt = tgt >= bi ? tgt : bi;
+        const int ti = min(tgt, np.N - 1);
+        T v_des = np.target_speed;
+        if (np.flags & SCCBF_NOMINAL_WAYPOINT_SPEED) v_des = traj4[ti].w;
+        T acc, delta;
+        stanley_pid_(np, st.z, st.w, sth, cth, fx, fy, c.x[(bi / kSub) * kSubStride + bi % kSub],
+                     c.y[(bi / kSub) * kSubStride + bi % kSub], s_yaw[ti], v_des, np.pid_state != nullptr, ps,
+                     acc, delta);
+        // filter
+        L.sv = st;
+        L.urv = v2{acc, delta};
+        Ego<T> e;
+        T ur0, ur1;
+        T at0[RPL], at1[RPL], bt[RPL];
+        T hm = INFINITY;
+        int bad = lane_rows_<T, RPL, false>(p, ag, g, G, false, L, e, ur0, ur1, at0, at1, bt, &hm);
+        bad = (int)group_or<G>((unsigned)bad);
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) {
+            s_rows[qslot + r * G + g] = at0[r];
+            s_rows[kPlane + qslot + r * G + g] = at1[r];
+            s_rows[2 * kPlane + qslot + r * G + g] = bt[r];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const Pivot<T> s = active_set_<T, G, RPL, true>(p.M, g, at0, at1, bt, s_rows, kPlane, qslot, bad);
+        __builtin_amdgcn_wave_barrier();  // the table is rewritten next tick
+        const v2 u = result_u_(p, false, s.st, s.w0, s.w1, e, ur0, ur1);
+        hm = min_(hm, __shfl_xor(hm, 1, 64));
+        hm = min_(hm, __shfl_xor(hm, 2, 64));
+        h_min = min_(h_min, hm);
+        n_act += (s.st == SCCBF_STATUS_OPTIMAL) & ((s.w0 != T(0)) | (s.w1 != T(0)));
+        n_inf += s.st == SCCBF_STATUS_INFEASIBLE;
+        // vehicle step, then the obstacles move
+        const T beta = vehicle_step_<T>(st, u.x, u.y, a.k_in, a.inv_lr, a.max_steer, a.dt);
+        if (a.trace && live && g == 0)
+            reinterpret_cast<v4*>(a.trace)[(long long)tick * p.A + ag] = v4{u.x, u.y, beta, (T)s.st};
+        if (a.motion == SCCBF_MOTION_CONSTANT_VELOCITY) {
+#pragma unroll
+            for (int r = 0; r < RPL; ++r) advance_slot_<T>(L.ty[r], L.oa[r], L.ob[r], a.dt);
+        }
+    }
+    if (live && g == 0) {
+        reinterpret_cast<v4*>(a.state)[ag] = st;
+        np.target_idx[ag] = tgt;
+        if (np.pid_state) reinterpret_cast<v2*>(np.pid_state)[ag] = ps;
+        if (a.h_min) a.h_min[ag] = h_min;
+        if (a.n_active) a.n_active[ag] = n_act;
+        if (a.n_infeasible) a.n_infeasible[ag] = n_inf;
+    }
 }
 
 // ------------------------------------------------------------------- host side
@@ -1277,6 +1475,17 @@ int qp_impl(const sccbf_params* sp, int64_t A, int32_t M, const T* rows, const T
 }
 
 template <typename T>
+void fill_nominal_args(const sccbf_nominal_params* sp, int64_t A, int32_t N, NArgs<T>& k)
+{
+    k.axle = (T)sp->axle; k.k = (T)sp->k; k.ks = (T)sp->ks;
+    k.kp = (T)sp->kp; k.ki = (T)sp->ki; k.kd = (T)sp->kd;
+    k.dt = (T)sp->dt; k.inv_dt = (T)(sp->dt > 0.0 ? 1.0 / sp->dt : 0.0);
+    k.target_speed = (T)sp->target_speed;
+    k.flags = sp->flags;
+    k.A = A; k.N = N;
+}
+
+template <typename T>
 int nominal_impl(const sccbf_nominal_params* sp, int64_t A, int32_t N, const T* state, const T* traj,
                  int32_t* target_idx, T* pid_state, T* u_ref, void* stream)
 {
@@ -1285,12 +1494,7 @@ int nominal_impl(const sccbf_nominal_params* sp, int64_t A, int32_t N, const T* 
     if (!state || !traj || !target_idx || !u_ref) return SCCBF_ERR_ARG;
     if (pid_state && !(sp->dt > 0.0)) return SCCBF_ERR_ARG;
     NArgs<T> k;
-    k.axle = (T)sp->axle; k.k = (T)sp->k; k.ks = (T)sp->ks;
-    k.kp = (T)sp->kp; k.ki = (T)sp->ki; k.kd = (T)sp->kd;
-    k.dt = (T)sp->dt; k.inv_dt = (T)(sp->dt > 0.0 ? 1.0 / sp->dt : 0.0);
-    k.target_speed = (T)sp->target_speed;
-    k.flags = sp->flags;
-    k.A = A; k.N = N;
+    fill_nominal_args<T>(sp, A, N, k);
     k.state = state; k.traj = traj; k.target_idx = target_idx; k.pid_state = pid_state; k.u_ref = u_ref;
     const long long per_block = kNomBlock / kNomLanes;
     const long long blocks = (A + per_block - 1) / per_block;
@@ -1308,9 +1512,56 @@ int vehicle_step_impl(int64_t A, T* state, const T* u, double lr, double lf, dou
     if (!state || !u) return SCCBF_ERR_ARG;
     const long long blocks = (A + kBlock - 1) / kBlock;
     hipLaunchKernelGGL((k_vehicle_step<T>), dim3((unsigned)blocks), dim3(kBlock), 0,
-                       reinterpret_cast<hipStream_t>(stream), (long long)A, state, u, (T)lr,
+                       reinterpret_cast<hipStream_t>(stream), (long long)A, state, u,
                        (T)(lr / (lf + lr)), (T)(1.0 / lr), (T)max_steer, (T)dt, beta_out);
     return hipGetLastError() == hipSuccess ? SCCBF_OK : SCCBF_ERR_LAUNCH;
+}
+
+template <typename T, int RPL>
+int launch_rollout(const RArgs<T>& r, hipStream_t s)
+{
+    const long long per_block = kBlock / kNomLanes;
+    const long long blocks = (r.f.A + per_block - 1) / per_block;
+    if (blocks > 0x7fffffffLL) return SCCBF_ERR_ARG;
+    hipLaunchKernelGGL((k_rollout<T, RPL>), dim3((unsigned)blocks), dim3(kBlock), 0, s, r);
+    return hipGetLastError() == hipSuccess ? SCCBF_OK : SCCBF_ERR_LAUNCH;
+}
+
+template <typename T>
+int rollout_impl(const sccbf_params* sp, const sccbf_nominal_params* np, const sccbf_rollout_params* rp,
+                 int64_t A, int32_t M, int32_t N, T* state, const T* traj, int32_t* target_idx, T* pid_state,
+                 const T* obs, const uint8_t* obs_type, T* h_min, int32_t* n_active, int32_t* n_infeasible,
+                 T* trace, void* stream)
+{
+    if (!np || !rp) return SCCBF_ERR_ARG;
+    RArgs<T> r;
+    int rc = fill_args<T>(sp, A, M, r.f);
+    if (rc != SCCBF_OK) return rc;
+    if (N > kTrajChunk || M > 16 * kNomLanes) return SCCBF_ERR_ROWS;
+    if (N < 1 || M < 1 || rp->ticks < 0 || !(rp->dt > 0.0) || !(rp->max_steer >= 0.0)) return SCCBF_ERR_ARG;
+    if (rp->motion != SCCBF_MOTION_STATIC && rp->motion != SCCBF_MOTION_CONSTANT_VELOCITY) return SCCBF_ERR_ARG;
+    if (sp->dynamics != SCCBF_DYN_DBM) return SCCBF_ERR_ARG;  // update_com is the DBM step
+    if (sp->flags & SCCBF_FLAG_OBS_SHARED) return SCCBF_ERR_ARG;  // moving obstacles are per agent
+    if (A == 0 || rp->ticks == 0) return SCCBF_OK;
+    if (!state || !traj || !target_idx || !obs || !obs_type) return SCCBF_ERR_ARG;
+    if (pid_state && !(np->dt > 0.0)) return SCCBF_ERR_ARG;
+    fill_nominal_args<T>(np, A, N, r.n);
+    r.f.state = state; r.f.u_ref = nullptr; r.f.obs = obs; r.f.obs_type = obs_type;
+    r.f.u_out = nullptr; r.f.status = nullptr; r.f.rows_out = nullptr;
+    r.n.state = state; r.n.traj = traj; r.n.target_idx = target_idx; r.n.pid_state = pid_state;
+    r.n.u_ref = state;  // placeholder for the loader's nominal-input read (overwritten every tick)
+    r.state = state;
+    r.k_in = (T)(sp->lr / (sp->lf + sp->lr)); r.inv_lr = (T)(1.0 / sp->lr);
+    r.max_steer = (T)rp->max_steer; r.dt = (T)rp->dt;
+    r.ticks = rp->ticks; r.motion = rp->motion;
+    r.h_min = h_min; r.n_active = n_active; r.n_infeasible = n_infeasible; r.trace = trace;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int rpl = (M + kNomLanes - 1) / kNomLanes;
+    if (rpl <= 1) return launch_rollout<T, 1>(r, s);
+    if (rpl <= 2) return launch_rollout<T, 2>(r, s);
+    if (rpl <= 4) return launch_rollout<T, 4>(r, s);
+    if (rpl <= 8) return launch_rollout<T, 8>(r, s);
+    return launch_rollout<T, 16>(r, s);
 }
 
 }  // namespace
@@ -1423,6 +1674,33 @@ int sccbf_vehicle_step_f64(int64_t A, double* state, const double* u, double lr,
                            double dt, double* beta_out, void* stream)
 {
     return vehicle_step_impl<double>(A, state, u, lr, lf, max_steer, dt, beta_out, stream);
+}
+
+void sccbf_default_rollout_params(sccbf_rollout_params* p)
+{
+    if (!p) return;
+    p->max_steer = 30.0 * 3.14159265358979323846 / 180.0;
+    p->dt = 0.1;
+    p->ticks = 0;
+    p->motion = SCCBF_MOTION_STATIC;
+}
+
+int sccbf_rollout_f32(const sccbf_params* p, const sccbf_nominal_params* np, const sccbf_rollout_params* rp,
+                      int64_t A, int32_t M, int32_t N, float* state, const float* traj, int32_t* target_idx,
+                      float* pid_state, const float* obs, const uint8_t* obs_type, float* h_min,
+                      int32_t* n_active, int32_t* n_infeasible, float* trace, void* stream)
+{
+    return rollout_impl<float>(p, np, rp, A, M, N, state, traj, target_idx, pid_state, obs, obs_type, h_min,
+                               n_active, n_infeasible, trace, stream);
+}
+
+int sccbf_rollout_f64(const sccbf_params* p, const sccbf_nominal_params* np, const sccbf_rollout_params* rp,
+                      int64_t A, int32_t M, int32_t N, double* state, const double* traj, int32_t* target_idx,
+                      double* pid_state, const double* obs, const uint8_t* obs_type, double* h_min,
+                      int32_t* n_active, int32_t* n_infeasible, double* trace, void* stream)
+{
+    return rollout_impl<double>(p, np, rp, A, M, N, state, traj, target_idx, pid_state, obs, obs_type, h_min,
+                                n_active, n_infeasible, trace, stream);
 }
 
 }  // extern "C"

@@ -115,6 +115,47 @@ class ClosedLoop:
         self.status = torch.empty((A,), dtype=torch.int32, device=dev)
         self.beta = torch.empty((A,), dtype=ty, device=dev)
 
+    def rollout(self, ticks, motion="static", trace=False):
+        """`ticks` ticks in ONE launch (sccbf_rollout_*): state, target_idx and pid_state advance in
+        place; obstacles may move with constant velocity inside the launch (`obs` itself is not written).
+        Returns a dict: h_min (A,), n_active (A,), n_infeasible (A,) and, if asked for,
+        trace (ticks, A, 4) = a*, delta*, beta, status per tick."""
+        A, dev, ty = self.state.shape[0], self.state.device, self.state.dtype
+        obs = self.obs
+        flags = self.cbf.params.flags & ~(_lib.FLAG_OBS_SHARED | _lib.FLAG_OBS_TILED | _lib.FLAG_TYPE_PER_AGENT)
+        if obs.dim() == 5:
+            flags |= _lib.FLAG_OBS_TILED
+            M = obs.shape[1]
+        elif obs.dim() == 4:
+            M = obs.shape[0]
+        else:
+            raise ValueError("rollout needs per-agent obstacle slots (planes or tiles)")
+        if self.obs_type.dim() == 2:
+            flags |= _lib.FLAG_TYPE_PER_AGENT
+        if self.cbf.slip_io:
+            raise ValueError("rollout works in the caller's coordinates (a, delta): slip_io must be off")
+        N = self.traj.shape[0]
+        rp = _lib.RolloutParams()
+        lib = _lib.load()
+        lib.sccbf_default_rollout_params(C.byref(rp))
+        rp.max_steer, rp.dt, rp.ticks = self.max_steer, self.dt, int(ticks)
+        rp.motion = {"static": _lib.MOTION_STATIC, "constant_velocity": _lib.MOTION_CONSTANT_VELOCITY}[motion]
+        out = dict(h_min=torch.empty((A,), dtype=ty, device=dev),
+                   n_active=torch.empty((A,), dtype=torch.int32, device=dev),
+                   n_infeasible=torch.empty((A,), dtype=torch.int32, device=dev))
+        if trace:
+            out["trace"] = torch.empty((int(ticks), A, 4), dtype=ty, device=dev)
+        self.cbf.params.flags = flags
+        fn = lib.sccbf_rollout_f32 if ty == torch.float32 else lib.sccbf_rollout_f64
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            rc = fn(C.byref(self.cbf.params), C.byref(self.nominal.params), C.byref(rp), A, M, N,
+                    _ptr(self.state), _ptr(self.traj), _ptr(self.target_idx), _ptr(self.pid_state), _ptr(obs),
+                    _ptr(self.obs_type), _ptr(out["h_min"]), _ptr(out["n_active"]), _ptr(out["n_infeasible"]),
+                    _ptr(out.get("trace")), C.c_void_p(stream))
+        _lib.check(rc)
+        return out
+
     def tick(self):
         self.nominal.control(self.state, self.traj, self.target_idx, self.pid_state, u_ref=self.u_ref)
         self.cbf.solve(self.state, self.u_ref, self.obs, self.obs_type, u_out=self.u, status=self.status)

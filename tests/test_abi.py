@@ -89,6 +89,31 @@ def test_nominal_and_vehicle_step_argument_validation(lib):
     assert lib.sccbf_vehicle_step_f64(2, nul, nul, 0.0, 1.45, 0.5, 0.1, nul, nul) == -1    # lr must be > 0
 
 
+def test_rollout_argument_validation(lib):
+    assert C.sizeof(_lib.RolloutParams) == 2 * 8 + 2 * 4
+    r = _lib.RolloutParams()
+    lib.sccbf_default_rollout_params(C.byref(r))
+    assert abs(r.max_steer - 0.5235987755982988) < 1e-15 and r.dt == 0.1 and (r.ticks, r.motion) == (0, 0)
+    p, q = _lib.Params(), _lib.NominalParams()
+    lib.sccbf_default_params(C.byref(p))
+    lib.sccbf_default_nominal_params(C.byref(q))
+    nul = (C.c_void_p(0),) * 11
+    r.ticks = 5
+    call = lambda A, M, N: lib.sccbf_rollout_f32(C.byref(p), C.byref(q), C.byref(r), A, M, N, *nul)
+    assert call(0, 4, 100) == 0                      # empty batch
+    assert call(8, 4, 100) == -1                     # null data
+    assert call(8, 4, 2049) == -2                    # course longer than one LDS pass
+    assert call(8, 65, 100) == -2                    # more slots than four lanes hold
+    assert call(8, 0, 100) == -1 and call(8, 4, 0) == -1
+    r.motion = 9
+    assert call(8, 4, 100) == -1
+    r.motion = 0
+    p.dynamics = 1
+    assert call(8, 4, 100) == -1                     # the vehicle step is the DBM one
+    p.dynamics = 0
+    assert lib.sccbf_rollout_f64(None, C.byref(q), C.byref(r), 8, 4, 100, *nul) == -1
+
+
 def test_no_cpu_fallback_in_front_end():
     """Without a GPU the batched front-end must refuse, not compute somewhere else."""
     import numpy as np

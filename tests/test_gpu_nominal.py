@@ -146,3 +146,128 @@ def test_c1_closed_loop_entirely_on_the_gpu():
     assert np.abs(beta_deg - ref).max() <= 1e-3
     _, beta_cpu, _ = replay.replay_stanley_cone()
     assert np.abs(beta_deg - beta_cpu).max() <= 1e-6
+
+
+def _advance_planes(obs, ty, dt):
+    """Constant-velocity obstacle motion on the (M,2,A,4) planes, as SCCBF_MOTION_CONSTANT_VELOCITY states it."""
+    for m, kind in enumerate(ty.tolist()):
+        if kind == _lib.OBS_ELLIPSE:
+            obs[m, 0, :, 0] += obs[m, 1, :, 1] * dt
+            obs[m, 0, :, 1] += obs[m, 1, :, 2] * dt
+        elif kind == _lib.OBS_CONE:
+            ang = obs[m, 0, :, 2] + obs[m, 1, :, 1]
+            obs[m, 0, :, 0] += obs[m, 0, :, 3] * torch.cos(ang) * dt
+            obs[m, 0, :, 1] += obs[m, 0, :, 3] * torch.sin(ang) * dt
+        elif kind == _lib.OBS_RADIAL:
+            obs[m, 0, :, 0] += obs[m, 1, :, 0] * dt
+            obs[m, 0, :, 1] += obs[m, 1, :, 1] * dt
+
+
+def _rollout_case(A, M, seed, dtype, tiled):
+    from sccav_cbf_amd import scenarios
+    from sccav_cbf_amd.batched import BatchedCBF, planes_to_tiled
+    from sccav_cbf_amd.nominal import BatchedNominal, ClosedLoop
+    traj = _course()
+    w = scenarios.monte_carlo(A, (M + 1) // 2, M // 2, seed, nominal="uniform")
+    rng = np.random.default_rng(seed)
+    at = rng.integers(0, traj.shape[0] - 300, A)
+    xy = np.stack([traj[at, 0] + rng.normal(0, 2, A), traj[at, 1] + rng.normal(0, 2, A)], axis=1)
+    w["obs"][:, 0, :, 0:2] += (xy - w["state"][:, 0:2])[None, :, :]
+    w["state"][:, 0:2] = xy
+    w["state"][:, 2] = traj[at, 2] + rng.normal(0, 0.2, A)
+    w["state"][:, 3] = rng.uniform(3, 12, A)
+
+    def make():
+        state = torch.from_numpy(w["state"]).to(DEV).to(dtype)
+        obs = torch.from_numpy(w["obs"]).to(DEV).to(dtype)
+        ty = torch.from_numpy(w["obs_type"]).to(DEV)
+        loop = ClosedLoop(BatchedCBF(alpha=1.0, R=np.diag([0.5, 0.5])),
+                          BatchedNominal(axle=2.9, k=0.5, ks=0.01, kp=1.0, ki=0.2, kd=0.02, dt=0.1),
+                          torch.from_numpy(traj).to(DEV).to(dtype), state,
+                          planes_to_tiled(obs) if tiled else obs, ty, use_pid_state=True)
+        return loop, obs, ty
+    return make
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("M,motion,tiled", [(16, "constant_velocity", True), (5, "static", False),
+                                           (33, "constant_velocity", False), (64, "static", True)])
+def test_rollout_equals_tick_by_tick(dtype, M, motion, tiled):
+    """sccbf_rollout_* (one launch) against nominal -> filter -> vehicle step -> obstacle motion
+    launched tick by tick: per-tick inputs, slip angle and status, final state, statistics."""
+    from sccav_cbf_amd.batched import planes_to_tiled
+    A, T = 300, 25
+    make = _rollout_case(A, M, 50 + M, dtype, tiled)
+    la, obs_a, ty = make()
+    tr = []
+    hmin = torch.full((A,), float("inf"), dtype=dtype, device=DEV)
+    nact = torch.zeros((A,), dtype=torch.int64, device=DEV)
+    ninf = torch.zeros((A,), dtype=torch.int64, device=DEV)
+    for _ in range(T):
+        la.nominal.control(la.state, la.traj, la.target_idx, la.pid_state, u_ref=la.u_ref)
+        u, st, rows = la.cbf.solve(la.state, la.u_ref, la.obs, ty, u_out=la.u, status=la.status, want_rows=True)
+        hmin = torch.minimum(hmin, rows[:, :, 3].min(dim=0).values)
+        # "the filter changed the input" = some row is violated at the nominal input (QP coordinates)
+        beta_ref = torch.atan2(1.45 * torch.tan(la.u_ref[:, 1]), torch.full_like(la.u_ref[:, 1], 2.9))
+        lhs = rows[:, :, 0] * la.u_ref[None, :, 0] + rows[:, :, 1] * beta_ref[None, :]
+        viol = ((rows[:, :, 2] - lhs) / (torch.hypot(rows[:, :, 0], rows[:, :, 1]) + 1e-300)).max(dim=0).values
+        nact += ((st == 0) & (viol > 1e-9)).long()
+        ninf += (st == 1).long()
+        from sccav_cbf_amd.nominal import vehicle_step
+        vehicle_step(la.state, la.u, lr=1.45, lf=1.45, max_steer=la.max_steer, dt=la.dt, beta_out=la.beta)
+        tr.append(torch.cat([u, la.beta[:, None], st.to(dtype)[:, None]], dim=1).clone())
+        if motion == "constant_velocity":
+            _advance_planes(obs_a, ty, la.dt)
+            la.obs = planes_to_tiled(obs_a) if tiled else obs_a
+    tr = torch.stack(tr)
+    lb, _, _ = make()
+    out = lb.rollout(T, motion=motion, trace=True)
+    torch.cuda.synchronize()
+    tol = 1e-7 if dtype == torch.float64 else 5e-3      # 25 closed-loop ticks amplify last-bit differences
+    same = (out["trace"][:, :, 3] == tr[:, :, 3]).all(dim=0)       # agents whose status history agrees
+    assert same.float().mean().item() >= (1.0 if dtype == torch.float64 else 0.97)
+    # fp32: an agent whose status differed on one tick (boundary of feasibility) took another path
+    # (a vertex on two nearly parallel rows gives inputs of 1e4 and more: errors scale with them)
+    scale = 1 + tr[:, :, :2].abs().amax(dim=(0, 2))
+    d = ((out["trace"][:, :, :3] - tr[:, :, :3]).abs().amax(dim=(0, 2)) / scale)[same].max().item()
+    assert d <= tol, d
+    assert ((lb.state - la.state).abs().amax(dim=1) / scale)[same].max().item() <= tol * 50
+    di = (lb.target_idx[same] - la.target_idx[same]).abs()
+    if dtype == torch.float64:
+        assert di.max().item() == 0
+    else:   # near-ties between way-points 0.1 m apart
+        assert di.max().item() <= 2 and (di == 0).float().mean().item() >= 0.97
+    assert ((lb.pid_state - la.pid_state).abs().amax(dim=1) / scale)[same].max().item() <= tol * 50
+    assert (out["h_min"][same] - hmin[same]).abs().max().item() <= tol * (1 + hmin[same].abs().max().item())
+    assert torch.equal(out["n_infeasible"][same].long(), ninf[same])
+    if dtype == torch.float64:
+        dn = (out["n_active"].long() - nact).abs()
+        assert dn.max().item() <= 1 and (dn == 0).float().mean().item() >= 0.99
+
+
+def test_c1_by_one_rollout_launch():
+    """The as-shipped scenario in ONE launch of 276 ticks (fp64): the slip-angle trace reproduces the
+    reference's beta_vs_time.mat."""
+    import os
+    from sccav_cbf_amd.batched import BatchedCBF, cone_slots, pack_obs
+    from sccav_cbf_amd.nominal import BatchedNominal, ClosedLoop
+    gold = np.load(os.path.join(replay.GOLDEN, "beta_vs_time.npz"))
+    ref = np.asarray(gold["beta_deg"]).reshape(-1)
+    traj = _course()
+    k = replay.scenario_constants(traj[:, 0], traj[:, 1])
+    A = 2
+    state = torch.tensor([[0.0, 5.0, np.radians(20.0), 10.0]] * A, dtype=torch.float64, device=DEV)
+    one = torch.ones((A,), dtype=torch.float64, device=DEV)
+    obs = pack_obs(cone_slots(one * k["o_cx"], one * k["o_cy"], one * 0.0, one * 0.0,
+                              one * (k["a_cone"] + 1.5))[None])
+    ty = torch.tensor([_lib.OBS_CONE], dtype=torch.uint8, device=DEV)
+    loop = ClosedLoop(BatchedCBF(alpha=1.0, lr=replay.LR, lf=replay.LF, R=np.diag([0.5, 0.5])),
+                      BatchedNominal(axle=replay.WHEELBASE, k=replay.K_STANLEY, ks=0.0, kp=replay.KP,
+                                     target_speed=k["target_speed"]),
+                      torch.from_numpy(traj).to(DEV), state, obs, ty, max_steer=replay.MAX_STEER, dt=replay.DT)
+    out = loop.rollout(len(ref) - 1, trace=True)
+    torch.cuda.synchronize()
+    beta_deg = np.concatenate([[0.0], np.degrees(out["trace"][:, 0, 2].cpu().numpy())])
+    assert np.abs(beta_deg - ref).max() <= 1e-3
+    assert int(out["n_active"][0]) == 59 and int(out["n_infeasible"][0]) == 0      # ticks with an active row
+    assert float(out["h_min"][0]) > -1e-6                                          # the barrier is never crossed

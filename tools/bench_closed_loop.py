@@ -34,6 +34,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--agents", type=int, default=65536)
     ap.add_argument("--dtype", default="f32")
+    ap.add_argument("--far", action="store_true", help="obstacles 1000 m away: no row ever active")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     dt = torch.float32 if args.dtype == "f32" else torch.float64
@@ -48,6 +49,8 @@ def main():
     xy = np.stack([cx[at] + rng.normal(0, 3, A), cy[at] + rng.normal(0, 3, A)], axis=1)
     w["obs"][:, 0, :, 0:2] += (xy - w["state"][:, 0:2])[None, :, :]
     w["state"][:, 0:2] = xy
+    if args.far:
+        w["obs"][:, 0, :, 0] += 1000.0
     w["state"][:, 2] = cyaw[at] + rng.normal(0, 0.3, A)
     state = torch.from_numpy(w["state"]).to(dt).to(dev)
     state0 = state.clone()
@@ -71,6 +74,34 @@ def main():
             for _ in range(10):
                 loop.tick()
         t_tick = timed(g.replay, 50) / 10
+        # the same ticks fused into one launch per 100
+        T = 100
+        loop.state.copy_(state0)
+        loop.target_idx.zero_()
+        loop.rollout(T)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 5
+        e0.record()
+        for _ in range(reps):
+            loop.state.copy_(state0)
+            loop.target_idx.zero_()
+            loop.rollout(T)
+        e1.record()
+        torch.cuda.synchronize()
+        t_roll = e0.elapsed_time(e1) * 1e3 / (reps * T)
+        e0.record()
+        for _ in range(reps):
+            loop.state.copy_(state0)
+            loop.target_idx.zero_()
+            loop.rollout(T, motion="constant_velocity")
+        e1.record()
+        torch.cuda.synchronize()
+        t_roll_cv = e0.elapsed_time(e1) * 1e3 / (reps * T)
+    print("   fused rollout (%d ticks per launch): %.2f us per tick (%.3e agent-ticks/s); with moving obstacles %.2f us"
+          % (T, t_roll, A / (t_roll * 1e-6), t_roll_cv))
+    with torch.cuda.stream(st):
+        pass
     print("A=%d N=%d %s: nominal %.2f us, filter %.2f us, vehicle step %.2f us, captured tick %.2f us "
           "(%.3e agent-ticks/s)" % (A, traj.shape[0], args.dtype, t_nom, t_flt, t_stp, t_tick, A / (t_tick * 1e-6)))
 
