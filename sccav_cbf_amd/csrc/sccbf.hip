@@ -41,6 +41,12 @@ constexpr int kTile = SCCBF_TILE;
 #ifndef SCCBF_ROLLOUT_WAVES
 #define SCCBF_ROLLOUT_WAVES 4
 #endif
+#ifndef SCCBF_CAP_PER_ROW
+#define SCCBF_CAP_PER_ROW 8
+#define SCCBF_CAP_BASE 32
+#endif
+// active-set steps allowed per QP: kCapPerRow * M + kCapBase (a QP that needs more is reported infeasible)
+constexpr int kCapPerRow = SCCBF_CAP_PER_ROW, kCapBase = SCCBF_CAP_BASE;
 constexpr int kLaneIters = 32;     // Newton iterations for the lane closest point
 constexpr int kLaneHalvings = 30;  // step halvings per iteration
 
@@ -689,7 +695,7 @@ __device__ inline Pivot<T> active_set_(int M, int g, const T (&at0)[RPL], const 
     unsigned idx[RPL];  // 255 - row index: ties in violation go to the lowest index
 #pragma unroll
     for (int r = 0; r < RPL; ++r) idx[r] = (unsigned)(255 - (r * G + g));
-    const int cap = 8 * M + 32;
+    const int cap = kCapPerRow * M + kCapBase;
     // One step: find the most violated row of the group, move the optimum onto it.
     // Returns false (wave-uniform) once no group of the wave has work left.
     auto step = [&](auto ns_max, bool first, int it) -> bool {
@@ -848,7 +854,7 @@ __global__ __launch_bounds__(WPB * 64) void k_wave(const KArgs<T> p)
 
     Pivot<T> s;
     s.reset(bad ? SCCBF_STATUS_NONFINITE : SCCBF_STATUS_OPTIMAL);
-    const int cap = 8 * M + 32;
+    const int cap = kCapPerRow * M + kCapBase;
     for (int it = 0;; ++it) {  // wave-uniform loop
         const T thr = Lim<T>::viol_tol * (abs_(s.w0) + abs_(s.w1)) + Lim<T>::tiny_n2;
         unsigned kbest = 0u;
