@@ -5,7 +5,8 @@ import subprocess
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
-SRC = os.path.join(_PKG, "csrc", "sccbf.hip")
+CSRC = os.path.join(_PKG, "csrc")
+SRC = os.path.join(CSRC, "sccbf.hip")      # the one translation unit; it includes the *.hip.h next to it
 HDR = os.path.join(_ROOT, "include", "sccbf.h")
 LIB_DIR = os.path.join(_PKG, "lib")
 LIB = os.path.join(LIB_DIR, "libsccbf.so")
@@ -23,7 +24,8 @@ def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(f) > t for f in (SRC, HDR))
+    deps = [HDR] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".hip.h"))]
+    return any(os.path.getmtime(f) > t for f in deps)
 
 
 def build_library(force=False, verbose=False):

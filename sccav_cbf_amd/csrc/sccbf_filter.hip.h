@@ -1,0 +1,344 @@
+// sccbf_filter.hip.h - the filter kernels: k_group, k_wave, k_partials, k_passthrough
+// Part of the sccbf library (one translation unit, see sccbf.hip); device code for gfx950.
+#pragma once
+#include "sccbf_rows.hip.h"
+
+namespace {
+
+// ------------------------------------------------- G lanes per QP, rows in registers
+// What one lane holds of one QP between its loads and its arithmetic.
+template <typename T, int RPL> struct LaneLoads {
+    typename VT<T>::v2 urv;
+    typename VT<T>::v4 sv;
+    typename VT<T>::v4 oa[RPL], ob[RPL];
+    int ty[RPL];
+};
+
+// Every load of lane g of QP `qp` is issued up front, in the order the arithmetic
+// consumes them (ego first, then slot by slot), as straight-line code: slots past M
+// re-read slot M-1 and are turned into empty rows afterwards.
+// NT: obstacle slots are loaded with the non-temporal hint (read once, not worth keeping in
+// L2 / Infinity Cache); pays off for batches much larger than those caches.
+// The lane's slots are m0, m0 + dm, ..., m0 + (RPL - 1) dm.
+template <typename T, int RPL, bool QP_ONLY, bool NT>
+__device__ inline void group_load_(const KArgs<T>& p, long long qp, int m0, int dm, LaneLoads<T, RPL>& L)
+{
+    using v4 = typename VT<T>::v4;
+    using v2 = typename VT<T>::v2;
+    const int M = p.M;
+    const bool type_pa = (p.flags & SCCBF_FLAG_TYPE_PER_AGENT) != 0;
+    const v4* obs4 = reinterpret_cast<const v4*>(p.obs);
+    L.urv = reinterpret_cast<const v2*>(p.u_ref)[qp];
+    L.sv = v4{T(0), T(0), T(0), T(0)};
+    if (!QP_ONLY) L.sv = reinterpret_cast<const v4*>(p.state)[qp];
+    const ObsAddr oad = obs_addr_(p, qp);
+    const unsigned tstr = type_pa ? (unsigned)p.A : 1u;
+    const unsigned long long toff = type_pa ? (unsigned long long)qp : 0ull;
+#pragma unroll
+    for (int r = 0; r < RPL; ++r) {
+        const int m = m0 + r * dm;
+        const int mm = m < M ? m : M - 1;
+        L.ty[r] = 0;
+        // keep the issue order (the vmcnt counter retires loads in order, so the order
+        // decides how early each row's arithmetic may start)
+        __builtin_amdgcn_sched_barrier(0);
+        if (QP_ONLY) {  // the host never launches this kernel with M = 0
+            L.oa[r] = obs4[(long long)mm * p.A + qp];
+            L.ob[r] = v4{T(0), T(0), T(0), T(0)};
+        } else {
+            const unsigned long long i0 = oad.at(mm);
+            L.ty[r] = p.obs_type[(unsigned long long)(unsigned)mm * tstr + toff];
+            if (NT) {
+                L.oa[r] = nt_load4_<T>(&obs4[i0]);
+                L.ob[r] = nt_load4_<T>(&obs4[i0 + oad.half]);
+            } else {
+                L.oa[r] = obs4[i0];
+                L.ob[r] = obs4[i0 + oad.half];
+            }
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// Rows of this lane (slots m0, m0 + dm, ...) from its loaded slots: unit normals in w-space.
+// Returns non-zero if the state, the nominal input or a row is not finite.
+template <typename T, int RPL, bool QP_ONLY>
+__device__ inline int lane_rows_(const KArgs<T>& p, long long qp, int m0, int dm, bool live,
+                                 const LaneLoads<T, RPL>& L, Ego<T>& e, T& ur0, T& ur1,
+                                 T (&at0)[RPL], T (&at1)[RPL], T (&bt)[RPL], T* h_min = nullptr)
+{
+    using v4 = typename VT<T>::v4;
+    const int M = p.M;
+    int bad;
+    make_ego_(p, L.sv, L.urv, QP_ONLY, e, ur0, ur1, bad);
+    T chk = T(0);  // stays 0 while every row is finite (x * 0 is NaN for Inf / NaN)
+#pragma unroll
+    for (int r = 0; r < RPL; ++r) {
+        const int m = m0 + r * dm;
+        T a0, a1, b, h;
+        if (QP_ONLY) {
+            a0 = L.oa[r].x; a1 = L.oa[r].y; b = L.oa[r].z; h = T(0);
+            if (m >= M) { a0 = T(0); a1 = T(0); b = T(-1); }
+        } else {
+            const T o[8] = {L.oa[r].x, L.oa[r].y, L.oa[r].z, L.oa[r].w,
+                            L.ob[r].x, L.ob[r].y, L.ob[r].z, L.ob[r].w};
+            const int ty = m < M ? L.ty[r] : SCCBF_OBS_EMPTY;
+            slot_row_(ty, o, e, p, a0, a1, b, h);
+            if (p.rows_out && m < M && live)
+                reinterpret_cast<v4*>(p.rows_out)[(long long)m * p.A + qp] = v4{a0, a1, b, h};
+            if (h_min && ty >= 0 && ty <= SCCBF_OBS_RADIAL) *h_min = min_(*h_min, h);  // real slots only
+        }
+        chk += a0 * T(0) + a1 * T(0) + b * T(0);
+        to_wspace_(a0, a1, b, e, p, at0[r], at1[r], bt[r]);
+    }
+    return bad | !(chk == T(0));
+}
+
+// Active-set iteration of a group of G lanes: lane g holds rows r G + g in registers; with
+// LDS_PICK all rows of the group's QP are also in LDS at s_rows[c * plane + qslot + m].
+template <typename T, int G, int RPL, bool LDS_PICK>
+__device__ inline Pivot<T> active_set_(int M, int g, const T (&at0)[RPL], const T (&at1)[RPL],
+                                       const T (&bt)[RPL], const T* s_rows, int plane, int qslot, int bad)
+{
+    // take the most violated row, move the optimum onto it
+    Pivot<T> s;
+    s.reset(bad ? SCCBF_STATUS_NONFINITE : SCCBF_STATUS_OPTIMAL);
+    unsigned idx[RPL];  // 255 - row index: ties in violation go to the lowest index
+#pragma unroll
+    for (int r = 0; r < RPL; ++r) idx[r] = (unsigned)(255 - (r * G + g));
+    const int cap = kCapPerRow * M + kCapBase;
+    // One step: find the most violated row of the group, move the optimum onto it.
+    // Returns false (wave-uniform) once no group of the wave has work left.
+    auto step = [&](auto ns_max, bool first, int it) -> bool {
+        // rows are unit-normal, so bt - a.w is a distance; below thr it is rounding
+        const T thr = Lim<T>::viol_tol * (abs_(s.w0) + abs_(s.w1)) + Lim<T>::tiny_n2;
+        // key = violation in the high bits, idx below: the maximum is the most violated
+        // row and the keys of a group are distinct.  Keys are compared as signed integers,
+        // so a row that is satisfied (negative violation) loses against any violated one.
+        int key[RPL];
+        int kbest = 0;
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) {
+            const T viol = first ? bt[r] : bt[r] - at0[r] * s.w0 - at1[r] * s.w1;
+            key[r] = (int)((viol_bits(viol, thr) & ~0xFFu) | idx[r]);
+            kbest = (r == 0 || key[r] > kbest) ? key[r] : kbest;  // always the key of a real slot
+        }
+        const int kmax = group_imax<G>(kbest);
+        const bool go = (s.st == SCCBF_STATUS_OPTIMAL) & viol_key_above(kmax, thr);
+        if (!__any(go)) return false;  // every group of the wave is done
+        if (it >= cap) {               // no convergence: rows numerically inconsistent
+            s.st = go ? SCCBF_STATUS_INFEASIBLE : s.st;
+            return false;
+        }
+        T c0 = T(0), c1 = T(0), cb = T(0);
+        if (LDS_PICK) {
+            const int at = qslot + 255 - (kmax & 0xFF);
+            c0 = s_rows[at];
+            c1 = s_rows[plane + at];
+            cb = s_rows[2 * plane + at];
+        } else {
+            // the lane that holds the winning row publishes it (the other lanes contribute 0)
+#pragma unroll
+            for (int r = 0; r < RPL; ++r) {
+                const bool sel = key[r] == kmax;
+                c0 = sel ? at0[r] : c0;
+                c1 = sel ? at1[r] : c1;
+                cb = sel ? bt[r] : cb;
+            }
+            if (G > 1) {
+                c0 = group_bcast<G>(c0);
+                c1 = group_bcast<G>(c1);
+                cb = group_bcast<G>(cb);
+            }
+        }
+        pivot_onto_<decltype(ns_max)::value>(s, c0, c1, cb, go);
+        return true;
+    };
+    // wave-uniform trip count, lanes commit under `go`; the first step starts from w = 0
+    // with no active row and the second one has at most one
+    if (step(std::integral_constant<int, 0>(), true, 0) && step(std::integral_constant<int, 1>(), false, 1)) {
+        for (int it = 2; step(std::integral_constant<int, 2>(), false, it); ++it) {}
+    }
+    return s;
+}
+
+// Rows of this lane from its loaded slots, then the active-set iteration of the group.
+template <typename T, int G, int RPL, bool QP_ONLY>
+__device__ inline void group_solve_(const KArgs<T>& p, long long qp, int g, const LaneLoads<T, RPL>& L)
+{
+    Ego<T> e;
+    T ur0, ur1;
+    T at0[RPL], at1[RPL], bt[RPL];
+    int bad = lane_rows_<T, RPL, QP_ONLY>(p, qp, g, G, true, L, e, ur0, ur1, at0, at1, bt);
+    bad = (int)group_or<G>((unsigned)bad);
+
+    // The rows also go to LDS, row m of the group's QP at [component][qp slot][m], so that
+    // the winning row of a step is one indexed read per component instead of a chain of
+    // selects over the registers of every lane.  Each wavefront reads only what it wrote.
+    constexpr int kMpad = G * RPL + 1;          // odd stride between QPs: fewer bank conflicts
+    constexpr int kPlane = (kBlock / G) * kMpad;
+    constexpr bool kLdsPick = (size_t)3 * kPlane * sizeof(T) <= 53 * 1024;  // 3 workgroups per CU at most
+    __shared__ T s_rows[kLdsPick ? 3 * kPlane : 1];
+    const int qslot = (int)(threadIdx.x / G) * kMpad;
+    if (kLdsPick) {
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) {
+            s_rows[qslot + r * G + g] = at0[r];
+            s_rows[kPlane + qslot + r * G + g] = at1[r];
+            s_rows[2 * kPlane + qslot + r * G + g] = bt[r];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    const Pivot<T> s = active_set_<T, G, RPL, kLdsPick>(p.M, g, at0, at1, bt, s_rows, kPlane, qslot, bad);
+    if (g == 0) store_result_(p, qp, QP_ONLY, s.st, s.w0, s.w1, e, ur0, ur1);
+}
+
+// The arguments every wave needs before it can issue its first loads come first and one
+// by one: the leading 16 dwords of the kernel arguments are preloaded into SGPRs at wave
+// launch (-amdgpu-kernarg-preload-count), which a by-value struct does not qualify for.
+template <typename T, int G, int RPL, bool QP_ONLY, bool NT>
+__global__ __launch_bounds__(kBlock) void k_group(long long A, const T* obs, const T* state, const T* u_ref,
+                                                  const uint8_t* obs_type, int M, unsigned flags,
+                                                  const KArgs<T> rest)
+{
+    KArgs<T> p = rest;
+    p.A = A; p.obs = obs; p.state = state; p.u_ref = u_ref; p.obs_type = obs_type; p.M = M; p.flags = flags;
+    const int g = (int)(threadIdx.x % G);
+    const long long qp = (long long)blockIdx.x * (kBlock / G) + threadIdx.x / G;
+    if (qp >= p.A) return;  // groups are lane-aligned: a whole group leaves together
+    LaneLoads<T, RPL> L;
+    group_load_<T, RPL, QP_ONLY, NT>(p, qp, g, G, L);
+    group_solve_<T, G, RPL, QP_ONLY>(p, qp, g, L);
+}
+
+// ------------------------------------------ one wavefront per QP, rows staged in LDS
+template <typename T, int WPB, bool QP_ONLY>
+__global__ __launch_bounds__(WPB * 64) void k_wave(const KArgs<T> p)
+{
+    using v4 = typename VT<T>::v4;
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    const int M = p.M;
+    T* s_at0 = reinterpret_cast<T*>(smem_raw) + (size_t)wv * 3 * M;
+    T* s_at1 = s_at0 + M;
+    T* s_bt = s_at1 + M;
+
+    long long qp = (long long)blockIdx.x * WPB + wv;
+    const bool live = qp < p.A;
+    if (!live) qp = p.A - 1;  // keep the wave for the block barrier; its stores are masked
+
+    const bool type_pa = (p.flags & SCCBF_FLAG_TYPE_PER_AGENT) != 0;
+    const v4* obs4 = reinterpret_cast<const v4*>(p.obs);
+    const ObsAddr oad = obs_addr_(p, qp);
+
+    Ego<T> e;
+    T ur0, ur1;
+    int bad;
+    load_ego_(p, qp, QP_ONLY, e, ur0, ur1, bad);
+
+    for (int m = lane; m < M; m += 64) {
+        T a0, a1, b, h;
+        if (QP_ONLY) {
+            const v4 rw = obs4[(long long)m * p.A + qp];
+            a0 = rw.x; a1 = rw.y; b = rw.z; h = T(0);
+        } else {
+            const long long i0 = oad.at(m);
+            const v4 oa = obs4[i0];
+            const v4 ob = obs4[i0 + oad.half];
+            const int ty = type_pa ? p.obs_type[(long long)m * p.A + qp] : p.obs_type[m];
+            const T o[8] = {oa.x, oa.y, oa.z, oa.w, ob.x, ob.y, ob.z, ob.w};
+            slot_row_(ty, o, e, p, a0, a1, b, h);
+            if (p.rows_out && live)
+                reinterpret_cast<v4*>(p.rows_out)[(long long)m * p.A + qp] = v4{a0, a1, b, h};
+        }
+        bad |= !(finite_(a0) && finite_(a1) && finite_(b));
+        T t0, t1, tb;
+        to_wspace_(a0, a1, b, e, p, t0, t1, tb);
+        s_at0[m] = t0;
+        s_at1[m] = t1;
+        s_bt[m] = tb;
+    }
+    bad = __any(bad);
+    __syncthreads();
+
+    Pivot<T> s;
+    s.reset(bad ? SCCBF_STATUS_NONFINITE : SCCBF_STATUS_OPTIMAL);
+    const int cap = kCapPerRow * M + kCapBase;
+    for (int it = 0;; ++it) {  // wave-uniform loop
+        const T thr = Lim<T>::viol_tol * (abs_(s.w0) + abs_(s.w1)) + Lim<T>::tiny_n2;
+        unsigned kbest = 0u;
+        for (int m = lane; m < M; m += 64) {
+            const T viol = s_bt[m] - (s_at0[m] * s.w0 + s_at1[m] * s.w1);
+            const unsigned key = viol > thr ? ((viol_bits_pos(viol) & ~0x3FFu) | (unsigned)(1023 - m)) : 0u;
+            kbest = key > kbest ? key : kbest;
+        }
+        const unsigned kmax = group_umax<64>(kbest);
+        const bool go = (s.st == SCCBF_STATUS_OPTIMAL) & (kmax != 0u);
+        if (!go) break;
+        if (it >= cap) {
+            s.st = SCCBF_STATUS_INFEASIBLE;
+            break;
+        }
+        const int sel = 1023 - (int)(kmax & 0x3FFu);
+        pivot_onto_(s, s_at0[sel], s_at1[sel], s_bt[sel], true);  // broadcast reads
+    }
+    const int st = s.st;
+    const T w0 = s.w0, w1 = s.w1;
+    if (lane == 0 && live) store_result_(p, qp, QP_ONLY, st, w0, w1, e, ur0, ur1);
+}
+
+// ------------------------------------- barrier value and partials only (no rows, no QP)
+// One thread per (slot, agent); out is T[M][2][A][4] = (h, h_x, h_y, h_theta | h_v, h_t, 0, 0).
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_partials(const KArgs<T> p)
+{
+    using v4 = typename VT<T>::v4;
+    const long long gid = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (gid >= p.A * p.M) return;
+    const int m = (int)(gid / p.A);
+    const long long a = gid % p.A;
+    const bool type_pa = (p.flags & SCCBF_FLAG_TYPE_PER_AGENT) != 0;
+    const v4* obs4 = reinterpret_cast<const v4*>(p.obs);
+    const ObsAddr oad = obs_addr_(p, a);
+    const long long i0 = oad.at(m);
+    const v4 oa = obs4[i0];
+    const v4 ob = obs4[i0 + oad.half];
+    const int ty = type_pa ? p.obs_type[(long long)m * p.A + a] : p.obs_type[m];
+    const v4 s = reinterpret_cast<const v4*>(p.state)[a];
+    T sth, cth;
+    sincos_(s.z, &sth, &cth);
+    const T o[8] = {oa.x, oa.y, oa.z, oa.w, ob.x, ob.y, ob.z, ob.w};
+    Partials<T> d;
+    switch (ty) {
+    case SCCBF_OBS_ELLIPSE: ellipse_(s.x, s.y, o, d); break;
+    case SCCBF_OBS_CONE: cone_(s.x, s.y, s.z, s.w, cth, sth, o, p.zero_tol, d); break;
+    case SCCBF_OBS_LANE: lane_(s.x, s.y, o, p.zero_tol, d); break;
+    case SCCBF_OBS_RADIAL: radial_(s.x, s.y, s.w, o, d); break;
+    default: d.h = T(1); d.hx = d.hy = d.hth = d.hv = d.ht = T(0); break;
+    }
+    v4* out = reinterpret_cast<v4*>(p.rows_out);
+    out[(long long)m * 2 * p.A + a] = v4{d.h, d.hx, d.hy, d.hth};
+    out[(long long)m * 2 * p.A + p.A + a] = v4{d.hv, d.ht, T(0), T(0)};
+}
+
+// ----------------------------------------- no rows at all: the nominal input is optimal
+template <typename T, bool QP_ONLY>
+__global__ __launch_bounds__(kBlock) void k_passthrough(const KArgs<T> p)
+{
+    using v4 = typename VT<T>::v4;
+    using v2 = typename VT<T>::v2;
+    const long long a = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (a >= p.A) return;
+    const v2 ur = reinterpret_cast<const v2*>(p.u_ref)[a];
+    bool ok = finite_(ur.x) && finite_(ur.y);
+    if (!QP_ONLY) {
+        const v4 s = reinterpret_cast<const v4*>(p.state)[a];
+        ok = ok && finite_(s.x) && finite_(s.y) && finite_(s.z) && finite_(s.w);
+    }
+    reinterpret_cast<v2*>(p.u_out)[a] = ur;
+    p.status[a] = ok ? SCCBF_STATUS_OPTIMAL : SCCBF_STATUS_NONFINITE;
+}
+
+}  // namespace

@@ -1,0 +1,388 @@
+// sccbf_loop.hip.h - nominal controller, vehicle step and the closed-loop rollout kernel
+// Part of the sccbf library (one translation unit, see sccbf.hip); device code for gfx950.
+#pragma once
+#include "sccbf_filter.hip.h"
+
+namespace {
+
+// ------------------------------------------- nominal input: Stanley steering + PID speed
+template <typename T> struct NArgs {
+    T axle, k, ks, kp, ki, kd, dt, inv_dt, target_speed;
+    unsigned flags;
+    long long A;
+    int N;
+    const T* state;
+    const T* traj;
+    int* target_idx;
+    T* pid_state;
+    T* u_ref;
+};
+
+constexpr int kTrajChunk = 2048;  // way-points staged in LDS per pass
+constexpr int kSub = 32;          // way-points per bounding box
+constexpr int kSubs = kTrajChunk / kSub;
+constexpr int kSubStride = kSub + 1;  // odd stride: groups scanning different runs hit different banks
+constexpr int kNomLanes = 4;          // lanes per agent in the nominal and rollout kernels
+constexpr int kNomBlock = 1024;       // threads per workgroup of the nominal kernel: 256 agents share one staging
+
+template <typename T> __device__ inline T wrap_pi_(T a)
+{
+    // reference cbf/utils.py:93-106 subtracts / adds 2 pi until the angle is in [-pi, pi]
+    constexpr T kPi = T(3.14159265358979323846), k2Pi = T(6.28318530717958647692);
+    a -= k2Pi * rint(a * (T(1) / k2Pi));
+    a = a > kPi ? a - k2Pi : a;
+    a = a < -kPi ? a + k2Pi : a;
+    return a;
+}
+
+// One pass (up to 2048 way-points) of the course in LDS: coordinates in runs of 32 and the
+// bounding box of every run (four extra empty boxes for the four-at-a-time walk).
+template <typename T> struct CoursePass {
+    T x[kSubs * kSubStride], y[kSubs * kSubStride];
+    T x0[kSubs + kNomLanes], x1[kSubs + kNomLanes], y0[kSubs + kNomLanes], y1[kSubs + kNomLanes];
+};
+
+// Every thread of a BLOCK-thread workgroup takes 2048 / BLOCK consecutive way-points of the
+// pass [base, base + n); 32 * BLOCK / 2048 neighbouring threads make one run and reduce its
+// box by shuffles.  Way-points past the end are infinitely far, runs past the end empty.
+// The caller puts a workgroup barrier before and after.
+template <typename T, int BLOCK>
+__device__ inline void stage_course_(CoursePass<T>& c, const typename VT<T>::v4* traj4, int base, int n)
+{
+    using v2 = typename VT<T>::v2;
+    constexpr int kPer = kTrajChunk / BLOCK;  // way-points per thread
+    constexpr int kThr = kSub / kPer;         // threads per run
+    static_assert(kPer * BLOCK == kTrajChunk && kThr * kPer == kSub && kThr <= 64, "block size");
+    T x0 = INFINITY, x1 = -INFINITY, y0 = INFINITY, y1 = -INFINITY;
+    const int r = threadIdx.x / kThr, j0 = (threadIdx.x % kThr) * kPer;
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+        const int i = threadIdx.x * kPer + j;
+        T x = INFINITY, y = INFINITY;
+        if (i < n) {
+            const v2 w = *reinterpret_cast<const v2*>(traj4 + base + i);
+            x = w.x; y = w.y;
+            x0 = min_(x0, x); x1 = max_(x1, x);
+            y0 = min_(y0, y); y1 = max_(y1, y);
+        }
+        c.x[r * kSubStride + j0 + j] = x;
+        c.y[r * kSubStride + j0 + j] = y;
+    }
+#pragma unroll
+    for (int m = 1; m < kThr; m *= 2) {
+        x0 = min_(x0, __shfl_xor(x0, m, 64)); x1 = max_(x1, __shfl_xor(x1, m, 64));
+        y0 = min_(y0, __shfl_xor(y0, m, 64)); y1 = max_(y1, __shfl_xor(y1, m, 64));
+    }
+    if (threadIdx.x % kThr == 0) {
+        c.x0[r] = x0; c.x1[r] = x1; c.y0[r] = y0; c.y1[r] = y1;
+    }
+    if (threadIdx.x < kNomLanes) {
+        c.x0[kSubs + threadIdx.x] = INFINITY; c.x1[kSubs + threadIdx.x] = -INFINITY;
+        c.y0[kSubs + threadIdx.x] = INFINITY; c.y1[kSubs + threadIdx.x] = -INFINITY;
+    }
+}
+
+// Nearest way-point of one staged pass to (fx, fy), by the four lanes of a group: they step
+// through the boxes four at a time and scan (eight way-points each) only the runs whose box
+// is not farther than lim, the best squared distance known so far (on entry: any upper bound
+// of the answer).  best / bi: this lane's nearest way-point so far (strict "<" in index
+// order, so the first index wins a tie).  Every group walks its own list of runs: a wavefront
+// pays for the longest list among its groups, not for their union.
+template <typename T>
+__device__ inline void nearest_in_pass_(const CoursePass<T>& c, T fx, T fy, int g, int base, int runs,
+                                        T& lim, T& best, int& bi)
+{
+    constexpr int G = kNomLanes;
+    for (int r = 0; r < runs;) {  // r and lim are the same in the four lanes of a group
+        // lane g looks at the box of run r + g (infinitely far when the run is empty)
+        const T dx = max_(max_(c.x0[r + g] - fx, fx - c.x1[r + g]), T(0));
+        const T dy = max_(max_(c.y0[r + g] - fy, fy - c.y1[r + g]), T(0));
+        // (a few ulps of slack: the box distance and the way-point distance round independently)
+        const unsigned hit = group_or<G>((dx * dx + dy * dy <= lim * (T(1) + T(8) * Lim<T>::eps)) ? 1u << g : 0u);
+        if (hit == 0u) {
+            r += G;
+            continue;
+        }
+        r += __ffs(hit) - 1;  // the first run of the four that can hold the answer
+#pragma unroll
+        for (int j = 0; j < kSub / G; ++j) {  // lane g: way-points 8 g .. 8 g + 7 of the run
+            const int jj = g * (kSub / G) + j;
+            const T ex = fx - c.x[r * kSubStride + jj], ey = fy - c.y[r * kSubStride + jj];
+            const T d = ex * ex + ey * ey;
+            const bool lt = d < best;
+            best = lt ? d : best;
+            bi = lt ? base + r * kSub + jj : bi;
+        }
+        // tighten the bound with the group's best so far
+        T m = best;
+        m = min_(m, __shfl_xor(m, 1, 64));
+        m = min_(m, __shfl_xor(m, 2, 64));
+        lim = min_(lim, m);
+        ++r;
+    }
+}
+
+// the group's answer: least distance, then least index
+template <typename T> __device__ inline int group_nearest_(T best, int bi, int N)
+{
+    T m = best;
+    m = min_(m, __shfl_xor(m, 1, 64));
+    m = min_(m, __shfl_xor(m, 2, 64));
+    int c = best == m ? bi : 0x7fffffff;
+    c = min(c, __shfl_xor(c, 1, 64));
+    c = min(c, __shfl_xor(c, 2, 64));
+    return min(c, N - 1);  // (non-finite state: no way-point compares nearer; any index will do)
+}
+
+// Stanley steering and PID speed control from the nearest way-point (xn, yn), the target
+// way-point's (yaw, v_des) and the PID state ps = (previous error, integral), updated in place.
+// Reference cbf/controllers.py:96-99, 118-119, 141-147, 173-180.
+template <typename T>
+__device__ inline void stanley_pid_(const NArgs<T>& p, T yaw, T v, T sth, T cth, T fx, T fy, T xn, T yn,
+                                    T yaw_des, T v_des, bool pid, typename VT<T>::v2& ps, T& acc, T& delta)
+{
+    // cross-track error projected on the axle direction (-cos(yaw + pi/2), -sin(yaw + pi/2)) = (sin yaw, -cos yaw)
+    const T err = (fx - xn) * sth - (fy - yn) * cth;
+    const T theta_e = wrap_pi_(yaw_des - yaw);
+    const T theta_d = atan2_(p.k * err, v + p.ks);
+    delta = theta_e + theta_d;
+    const T vt = (p.flags & SCCBF_NOMINAL_WAYPOINT_SPEED) ? v_des : p.target_speed;
+    const T e = vt - v;
+    acc = p.kp * e;
+    if (pid) {
+        const T de = (e - ps.x) * p.inv_dt;
+        ps.y += p.dt * e;
+        acc = p.kp * e + p.ki * ps.y + p.kd * de;
+        ps.x = e;
+    }
+}
+
+// Four lanes per agent.  The nearest way-point is searched over the whole course
+// (controllers.py:89-93: np.argmin of np.hypot, first index on ties; squared distances order
+// the same way), exactly but not exhaustively: the workgroup stages the course through LDS
+// 2048 way-points at a time together with the bounding box of every run of 32, and the
+// distance to last tick's target way-point bounds the answer from above (nearest_in_pass_).
+template <typename T>
+__global__ __launch_bounds__(kNomBlock) void k_nominal(const NArgs<T> p)
+{
+    using v4 = typename VT<T>::v4;
+    using v2 = typename VT<T>::v2;
+    constexpr int G = kNomLanes;
+    __shared__ CoursePass<T> c;
+    const int g = threadIdx.x % G;
+    long long a = (long long)blockIdx.x * (kNomBlock / G) + threadIdx.x / G;
+    const bool live = a < p.A;
+    if (!live) a = p.A - 1;  // stays for the barriers; stores are masked
+    const v4* traj4 = reinterpret_cast<const v4*>(p.traj);
+    const v4 s = reinterpret_cast<const v4*>(p.state)[a];
+    T sth, cth;
+    sincos_(s.z, &sth, &cth);
+    const T fx = s.x + p.axle * cth, fy = s.y + p.axle * sth;
+    const int last = p.target_idx[a];
+    // upper bound of the answer: the distance to the way-point targeted last tick
+    T lim;
+    {
+        const v2 wl = *reinterpret_cast<const v2*>(traj4 + min(max(last, 0), p.N - 1));
+        lim = (fx - wl.x) * (fx - wl.x) + (fy - wl.y) * (fy - wl.y);
+    }
+    T best = INFINITY;
+    int bi = 0x7fffffff;
+    for (int base = 0; base < p.N; base += kTrajChunk) {
+        const int n = min(kTrajChunk, p.N - base);
+        __syncthreads();
+        stage_course_<T, kNomBlock>(c, traj4, base, n);
+        __syncthreads();
+        nearest_in_pass_(c, fx, fy, g, base, (n + kSub - 1) / kSub, lim, best, bi);
+    }
+    bi = group_nearest_(best, bi, p.N);
+    const v4 wn = traj4[bi];
+    const int idx = last >= bi ? last : bi;  // controllers.py:118-119
+    const v4 wt = traj4[min(idx, p.N - 1)];
+    v2 ps = v2{T(0), T(0)};
+    if (p.pid_state) ps = reinterpret_cast<v2*>(p.pid_state)[a];
+    T acc, delta;
+    stanley_pid_(p, s.z, s.w, sth, cth, fx, fy, wn.x, wn.y, wt.z, wt.w, p.pid_state != nullptr, ps, acc, delta);
+    if (live && g == 0) {
+        if (p.pid_state) reinterpret_cast<v2*>(p.pid_state)[a] = ps;
+        p.target_idx[a] = idx;
+        reinterpret_cast<v2*>(p.u_ref)[a] = v2{acc, delta};
+    }
+}
+
+// ------------------------------------------------------- vehicle step (update_com)
+// State.update_com, reference test_scripts/stanley_controller_ellipse.py:122-131; returns beta.
+template <typename T>
+__device__ inline T vehicle_step_(typename VT<T>::v4& s, T acc, T delta_in, T k_in, T inv_lr, T max_steer, T dt)
+{
+    const T delta = min_(max_(delta_in, -max_steer), max_steer);
+    const T beta = atan_(tan_(delta) * k_in);  // atan2(lr tan(delta), lf + lr), lf + lr > 0
+    T sth, cth;
+    sincos_(s.z, &sth, &cth);
+    const T v = s.w;
+    s.x += (v * cth - v * sth * beta) * dt;
+    s.y += (v * sth + v * cth * beta) * dt;
+    s.z += (v * beta * inv_lr) * dt;
+    s.w += acc * dt;
+    return beta;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_vehicle_step(long long A, T* state, const T* u, T k_in,
+                                                         T inv_lr, T max_steer, T dt, T* beta_out)
+{
+    using v4 = typename VT<T>::v4;
+    using v2 = typename VT<T>::v2;
+    const long long a = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (a >= A) return;
+    v4 s = reinterpret_cast<v4*>(state)[a];
+    const v2 in = reinterpret_cast<const v2*>(u)[a];
+    const T beta = vehicle_step_<T>(s, in.x, in.y, k_in, inv_lr, max_steer, dt);
+    reinterpret_cast<v4*>(state)[a] = s;
+    if (beta_out) beta_out[a] = beta;
+}
+
+// ---------------------------------------------------- closed-loop rollout in one launch
+template <typename T> struct RArgs {
+    KArgs<T> f;   // filter: parameters, obs, obs_type, M, flags (state / u_ref / u_out / status unused)
+    NArgs<T> n;   // nominal: parameters, traj, N, target_idx (in/out), pid_state (in/out)
+    T* state;     // [A][4] in/out
+    T k_in, inv_lr, max_steer, dt;
+    int ticks;
+    int motion;   // SCCBF_MOTION_*
+    T* h_min;     // [A] optional
+    int* n_active;      // [A] optional
+    int* n_infeasible;  // [A] optional
+    T* trace;     // [ticks][A][4] optional
+};
+
+// obstacle slots move between ticks (constant velocity): ellipse by (vx, vy), collision cone by
+// v_o along theta_o + beta, radial by (cdot_x, cdot_y); lanes and empty slots stay
+template <typename T>
+__device__ inline void advance_slot_(int type, typename VT<T>::v4& oa, typename VT<T>::v4& ob, T dt)
+{
+    if (type == SCCBF_OBS_ELLIPSE) {
+        oa.x += ob.y * dt;
+        oa.y += ob.z * dt;
+    } else if (type == SCCBF_OBS_CONE) {
+        T so, co;
+        sincos_(oa.z + ob.y, &so, &co);
+        oa.x += oa.w * co * dt;
+        oa.y += oa.w * so * dt;
+    } else if (type == SCCBF_OBS_RADIAL) {
+        oa.x += ob.x * dt;
+        oa.y += ob.y * dt;
+    }
+}
+
+// `ticks` control ticks of nominal controller -> filter -> vehicle step (-> obstacle motion)
+// for every agent in ONE launch: four lanes per agent, the agent's state, its obstacle slots
+// (four per lane), target index and PID state stay in registers, the course (at most 2048
+// way-points) and its run boxes are staged in LDS once per workgroup, the rows of each tick go
+// through the per-wavefront LDS table of the 4-lane filter kernel.  No HBM traffic inside the
+// loop except the optional trace.
+template <typename T, int RPL>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SCCBF_ROLLOUT_WAVES, SCCBF_ROLLOUT_WAVES)))
+void k_rollout(const RArgs<T> a)
+{
+    using v4 = typename VT<T>::v4;
+    using v2 = typename VT<T>::v2;
+    constexpr int G = kNomLanes;
+    constexpr int kMpad = G * RPL + 1;
+    constexpr int kPlane = (kBlock / G) * kMpad;
+    __shared__ CoursePass<T> c;
+    __shared__ T s_yaw[kTrajChunk];
+    __shared__ T s_rows[3 * kPlane];
+    const KArgs<T>& p = a.f;
+    const NArgs<T>& np = a.n;
+    const int g = threadIdx.x % G;
+    long long ag = (long long)blockIdx.x * (kBlock / G) + threadIdx.x / G;
+    const bool live = ag < p.A;
+    if (!live) ag = p.A - 1;  // stays for the barrier; stores are masked
+    const int qslot = (int)(threadIdx.x / G) * kMpad;
+    const v4* traj4 = reinterpret_cast<const v4*>(np.traj);
+
+    stage_course_<T, kBlock>(c, traj4, 0, np.N);
+    for (int i = threadIdx.x; i < np.N; i += kBlock) s_yaw[i] = traj4[i].z;
+
+    // this lane's obstacle slots (r G + g) and everything the agent carries from tick to tick
+    LaneLoads<T, RPL> L;
+    {
+        KArgs<T> q = p;
+        q.state = a.state;
+        q.u_ref = np.u_ref;  // any readable (A, 2) array: overwritten below before use
+        group_load_<T, RPL, false, false>(q, ag, g, G, L);
+    }
+    v4 st = L.sv;
+    int tgt = np.target_idx[ag];
+    v2 ps = v2{T(0), T(0)};
+    if (np.pid_state) ps = reinterpret_cast<v2*>(np.pid_state)[ag];
+    T h_min = INFINITY;
+    int n_act = 0, n_inf = 0;
+    __syncthreads();
+    const int runs = (np.N + kSub - 1) / kSub;
+
+    for (int tick = 0; tick < a.ticks; ++tick) {
+        // nominal input
+        T sth, cth;
+        sincos_(st.z, &sth, &cth);
+        const T fx = st.x + np.axle * cth, fy = st.y + np.axle * sth;
+        const int lt = min(max(tgt, 0), np.N - 1);
+        const T lx = c.x[(lt / kSub) * kSubStride + lt % kSub], ly = c.y[(lt / kSub) * kSubStride + lt % kSub];
+        T lim = (fx - lx) * (fx - lx) + (fy - ly) * (fy - ly);
+        T best = INFINITY;
+        int bi = 0x7fffffff;
+        nearest_in_pass_(c, fx, fy, g, 0, runs, lim, best, bi);
+        bi = group_nearest_(best, bi, np.N);
+        tgt = tgt >= bi ? tgt : bi;
+        const int ti = min(tgt, np.N - 1);
+        T v_des = np.target_speed;
+        if (np.flags & SCCBF_NOMINAL_WAYPOINT_SPEED) v_des = traj4[ti].w;
+        T acc, delta;
+        stanley_pid_(np, st.z, st.w, sth, cth, fx, fy, c.x[(bi / kSub) * kSubStride + bi % kSub],
+                     c.y[(bi / kSub) * kSubStride + bi % kSub], s_yaw[ti], v_des, np.pid_state != nullptr, ps,
+                     acc, delta);
+        // filter
+        L.sv = st;
+        L.urv = v2{acc, delta};
+        Ego<T> e;
+        T ur0, ur1;
+        T at0[RPL], at1[RPL], bt[RPL];
+        T hm = INFINITY;
+        int bad = lane_rows_<T, RPL, false>(p, ag, g, G, false, L, e, ur0, ur1, at0, at1, bt, &hm);
+        bad = (int)group_or<G>((unsigned)bad);
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) {
+            s_rows[qslot + r * G + g] = at0[r];
+            s_rows[kPlane + qslot + r * G + g] = at1[r];
+            s_rows[2 * kPlane + qslot + r * G + g] = bt[r];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const Pivot<T> s = active_set_<T, G, RPL, true>(p.M, g, at0, at1, bt, s_rows, kPlane, qslot, bad);
+        __builtin_amdgcn_wave_barrier();  // the table is rewritten next tick
+        const v2 u = result_u_(p, false, s.st, s.w0, s.w1, e, ur0, ur1);
+        hm = min_(hm, __shfl_xor(hm, 1, 64));
+        hm = min_(hm, __shfl_xor(hm, 2, 64));
+        h_min = min_(h_min, hm);
+        n_act += (s.st == SCCBF_STATUS_OPTIMAL) & ((s.w0 != T(0)) | (s.w1 != T(0)));
+        n_inf += s.st == SCCBF_STATUS_INFEASIBLE;
+        // vehicle step, then the obstacles move
+        const T beta = vehicle_step_<T>(st, u.x, u.y, a.k_in, a.inv_lr, a.max_steer, a.dt);
+        if (a.trace && live && g == 0)
+            reinterpret_cast<v4*>(a.trace)[(long long)tick * p.A + ag] = v4{u.x, u.y, beta, (T)s.st};
+        if (a.motion == SCCBF_MOTION_CONSTANT_VELOCITY) {
+#pragma unroll
+            for (int r = 0; r < RPL; ++r) advance_slot_<T>(L.ty[r], L.oa[r], L.ob[r], a.dt);
+        }
+    }
+    if (live && g == 0) {
+        reinterpret_cast<v4*>(a.state)[ag] = st;
+        np.target_idx[ag] = tgt;
+        if (np.pid_state) reinterpret_cast<v2*>(np.pid_state)[ag] = ps;
+        if (a.h_min) a.h_min[ag] = h_min;
+        if (a.n_active) a.n_active[ag] = n_act;
+        if (a.n_infeasible) a.n_infeasible[ag] = n_inf;
+    }
+}
+
+}  // namespace

@@ -1,0 +1,295 @@
+// sccbf_rows.hip.h - barrier functions of the obstacle kinds, constraint rows, ego quantities
+// Part of the sccbf library (one translation unit, see sccbf.hip); device code for gfx950.
+#pragma once
+#include "sccbf_qp.hip.h"
+
+namespace {
+
+// --------------------------------------------------------------------- barriers
+template <typename T> struct Partials {
+    T h, hx, hy, hth, hv, ht;
+};
+
+// Ellipse2D, reference cbf/obstacles.py:183-236, 310-317 (dt as written: no rotation).
+template <typename T>
+__device__ inline void ellipse_(T x, T y, const T o[8], Partials<T>& r)
+{
+    T xd = x - o[0], yd = y - o[1];
+    T ia2 = rcp_(o[2] * o[2]), ib2 = rcp_(o[3] * o[3]);
+    T st, ct;
+    sincos_(o[4], &st, &ct);
+    T p = xd * ct + yd * st;
+    T q = -xd * st + yd * ct;
+    r.h = p * p * ia2 + q * q * ib2 - T(1);
+    r.hx = T(2) * (ct * ia2 * p - st * ib2 * q);
+    r.hy = T(2) * (st * ia2 * p + ct * ib2 * q);
+    r.hth = T(0);
+    r.hv = T(0);
+    r.ht = T(-2) * (xd * ia2 * o[5] + yd * ib2 * o[6]);
+}
+
+// Time-varying ellipse with speed margin, reference
+// test_scripts/radial_dynamic_obstacles.py:391-405.
+template <typename T>
+__device__ inline void radial_(T x, T y, T v, const T o[8], Partials<T>& r)
+{
+    T xd = x - o[0], yd = y - o[1];
+    T ia2 = rcp_(o[2] * o[2]), ib2 = rcp_(o[3] * o[3]);
+    T iv = rcp_(T(1) + v);
+    r.h = xd * xd * ia2 + yd * yd * ib2 - T(1) - o[6] * v * iv;
+    r.hx = T(2) * xd * ia2;
+    r.hy = T(2) * yd * ib2;
+    r.hth = T(0);
+    r.hv = -o[6] * iv * iv;
+    r.ht = T(-2) * (xd * ia2 * o[4] + yd * ib2 * o[5]);
+}
+
+// CollisionCone2D, reference cbf/obstacles.py:468-502 (state), 401-458 (partials).
+template <typename T>
+__device__ inline void cone_(T x, T y, T th, T v, T cth, T sth, const T o[8], T eps,
+                             Partials<T>& r)
+{
+    T xd = x - o[0], yd = y - o[1];
+    T beta = o[5], a = o[4];
+    T svx = v * cth, svy = v * sth;
+    T so, co;
+    sincos_(o[2] + beta, &so, &co);
+    T ovx = o[3] * co, ovy = o[3] * so;
+    T dvx = svx - ovx, dvy = svy - ovy;
+    T d2 = xd * xd + yd * yd;
+    T dist = sqrt_(d2);
+    T vn = sqrt_(dvx * dvx + dvy * dvy);
+    T cb = eps;
+    if (dist > abs_(a)) cb = sqrt_(d2 - a * a) + eps;
+    T cos_phi = (dist > eps) ? div_(cb, dist) : T(0);
+    T c = cth, sn = sth;
+    if (beta != T(0)) sincos_(th + beta, &sn, &c);
+    T icb = rcp_(cb + eps);
+    T cbn = div_(cb, vn + eps);
+    r.h = (xd * dvx + yd * dvy) + dist * vn * cos_phi;
+    r.hx = dvx + vn * xd * icb;
+    r.hy = dvy + vn * yd * icb;
+    r.hv = (xd * c + yd * sn) + (dvx * c + dvy * sn) * cbn;
+    r.hth = (-xd * svy + yd * svx) + (-dvx * svy + dvy * svx) * cbn;
+    r.ht = (-dvx * ovx - dvy * ovy) - vn * (xd * ovx + yd * ovy) * icb;
+}
+
+template <typename T> __device__ inline void poly3_(const T c[4], T x, T& f, T& df, T& ddf)
+{
+    f = c[0] + x * (c[1] + x * (c[2] + x * c[3]));
+    df = c[1] + x * (T(2) * c[2] + x * T(3) * c[3]);
+    ddf = T(2) * c[2] + T(6) * c[3] * x;
+}
+
+// Abscissa of the curve point nearest to (px, py): descent from x0 = px, Newton with
+// the true curvature, halving until the distance does not grow.  Replaces the scipy
+// Newton-CG call of PolyLane.get_shortest_distance_x, reference cbf/obstacles.py:641-679.
+// Kept out of line (one copy, rolled loops): lanes are a minority of the rows and the
+// iteration would otherwise be replicated into every unrolled row of the kernels.
+template <typename T>
+__device__ __noinline__ T lane_closest_x_(T c0, T c1, T c2, T c3, T px, T py)
+{
+    const T c[4] = {c0, c1, c2, c3};
+    T x = px;
+#pragma nounroll
+    for (int it = 0; it < kLaneIters; ++it) {
+        T f, df, ddf;
+        poly3_(c, x, f, df, ddf);
+        T rr = f - py;
+        T g0 = (x - px) * (x - px) + rr * rr;
+        T g1 = T(2) * (x - px) + T(2) * rr * df;
+        T g2 = T(2) * (T(1) + df * df + rr * ddf);
+        T step = (g2 > T(1e-12)) ? div_(-g1, g2) : div_(-g1, abs_(g2) + T(1));
+        if (step == T(0)) break;
+        T xn = x + step;
+        T glim = g0 * (T(1) + T(8) * Lim<T>::eps);
+#pragma nounroll
+        for (int k = 0; k < kLaneHalvings; ++k) {
+            T fn, dfn, ddfn;
+            poly3_(c, xn, fn, dfn, ddfn);
+            T gn = (xn - px) * (xn - px) + (fn - py) * (fn - py);
+            if (gn <= glim) break;
+            step *= T(0.5);
+            xn = x + step;
+        }
+        x = xn;
+        if (abs_(step) <= Lim<T>::lane_xtol * (T(1) + abs_(x))) break;
+    }
+    return x;
+}
+
+// PolyLane, reference cbf/obstacles.py:620-636, 607-612, 681-689 (eta and the
+// un-squared buffer as written).
+template <typename T>
+__device__ inline void lane_(T x, T y, const T o[8], T eps, Partials<T>& r)
+{
+    T cx = lane_closest_x_(o[0], o[1], o[2], o[3], x, y);
+    T g, dg, ddg;
+    const T c[4] = {o[0], o[1], o[2], o[3]};
+    poly3_(c, cx, g, dg, ddg);
+    T eta = T(1) + dg * ddg + dg * dg - y * ddg;
+    if (abs_(eta) < eps) eta = eps;
+    T ie = div_(T(2), eta);
+    r.h = (cx - x) * (cx - x) + (g - y) * (g - y) - o[4];
+    r.hx = ie * ((x - cx) * (eta - T(1)) - (y - g) * dg);
+    r.hy = ie * (-(x - cx) * dg + (y - g) * (eta - dg * dg));
+    r.hth = T(0);
+    r.hv = T(0);
+    r.ht = T(0);
+}
+
+// Per-agent quantities every row needs.
+template <typename T> struct Ego {
+    T x, y, th, v, cth, sth;
+    T un0, un1;  // nominal input in QP coordinates
+};
+
+// Where the two 4-vectors of slot m of agent a live, in units of 4-vectors:
+//   planes (default)  obs[m][h][a]            index = a + m * 2A + h * A
+//   tiled             obs[a/64][m][h][a%64]   index = (a/64) * 128 M + a%64 + m * 128 + h * 64
+//   shared            obs[m][h]               index = m * 2 + h
+// The strides are 32-bit (2 A < 2^32) so that base + m * slot is one 64-bit multiply-add.
+struct ObsAddr {
+    unsigned long long base;
+    unsigned slot, half;
+    __device__ unsigned long long at(int m) const { return base + (unsigned long long)(unsigned)m * slot; }
+};
+template <typename T> __device__ inline ObsAddr obs_addr_(const KArgs<T>& p, long long a)
+{
+    ObsAddr r;
+    const bool shared = (p.flags & SCCBF_FLAG_OBS_SHARED) != 0;
+    const bool tiled = (p.flags & SCCBF_FLAG_OBS_TILED) != 0;
+    r.base = shared ? 0ull : (tiled ? (unsigned long long)(a / kTile) * (unsigned)(2 * kTile * p.M) + (unsigned)(a % kTile)
+                                    : (unsigned long long)a);
+    r.slot = shared ? 2u : (tiled ? 2u * kTile : 2u * (unsigned)p.A);
+    r.half = shared ? 1u : (tiled ? (unsigned)kTile : (unsigned)p.A);
+    return r;
+}
+
+// One obstacle slot -> constraint row  a . u >= b  (u-space) and barrier value h.
+// DBM contraction: reference cbf/cbf.py:159-164, 200-207.  KBM: cbf/cbf.py:94-101.
+template <typename T>
+__device__ inline void slot_row_(int type, const T o[8], const Ego<T>& e, const KArgs<T>& p,
+                                 T& a0, T& a1, T& b, T& h)
+{
+    Partials<T> d;
+    switch (type) {
+    case SCCBF_OBS_ELLIPSE: ellipse_(e.x, e.y, o, d); break;
+    case SCCBF_OBS_CONE: cone_(e.x, e.y, e.th, e.v, e.cth, e.sth, o, p.zero_tol, d); break;
+    case SCCBF_OBS_LANE: lane_(e.x, e.y, o, p.zero_tol, d); break;
+    case SCCBF_OBS_RADIAL: radial_(e.x, e.y, e.v, o, d); break;
+    default:
+        a0 = T(0); a1 = T(0); b = T(-1); h = T(1);
+        return;
+    }
+    h = d.h;
+    if (p.dynamics == SCCBF_DYN_KBM) {
+        a0 = e.cth * d.hx + e.sth * d.hy;
+        a1 = d.hth;
+        b = -(p.alpha * d.h);
+    } else {
+        a0 = d.hv;
+        a1 = e.v * (-e.sth * d.hx + e.cth * d.hy) + (e.v * p.inv_lr) * d.hth;
+        T lf_h = e.v * (e.cth * d.hx + e.sth * d.hy);
+        b = -(lf_h + p.alpha * d.h + d.ht);
+    }
+}
+
+// u-space row -> unit-normal row in w-space; zero rows keep at = 0.
+template <typename T>
+__device__ inline void to_wspace_(T a0, T a1, T b, const Ego<T>& e, const KArgs<T>& p,
+                                  T& at0, T& at1, T& bt)
+{
+    T t0 = a0 * p.inv_l00;
+    T t1 = (a1 - p.l10 * t0) * p.inv_l11;
+    T rhs = b - (a0 * e.un0 + a1 * e.un1);
+    T n2 = t0 * t0 + t1 * t1;
+    if (n2 > Lim<T>::tiny_n2) {
+        T inv = rsqrt_(n2);
+        at0 = t0 * inv;
+        at1 = t1 * inv;
+        bt = rhs * inv;
+    } else {
+        at0 = T(0);
+        at1 = T(0);
+        bt = rhs;
+    }
+}
+
+// Ego quantities from the already loaded state / nominal-input vectors.
+template <typename T>
+__device__ inline void make_ego_(const KArgs<T>& p, const typename VT<T>::v4& s,
+                                 const typename VT<T>::v2& ur, bool qp_only, Ego<T>& e,
+                                 T& ur0, T& ur1, int& bad)
+{
+    ur0 = ur.x;
+    ur1 = ur.y;
+    bad = !(finite_(ur0) && finite_(ur1));
+    if (qp_only) {
+        e.x = e.y = e.th = e.v = T(0);
+        e.cth = T(1);
+        e.sth = T(0);
+        e.un0 = ur0;
+        e.un1 = ur1;
+        return;
+    }
+    e.x = s.x; e.y = s.y; e.th = s.z; e.v = s.w;
+    bad |= !(finite_(s.x) && finite_(s.y) && finite_(s.z) && finite_(s.w));
+    sincos_(e.th, &e.sth, &e.cth);
+    e.un0 = ur0;
+    if (p.flags & SCCBF_FLAG_SLIP_IO)
+        e.un1 = ur1;
+    else if (p.dynamics == SCCBF_DYN_KBM)
+        e.un1 = ur0 * tan_(ur1) * p.inv_L;                       // reference cbf/cbf.py:75
+    else
+        e.un1 = atan_(tan_(ur1) * p.k_in);   // atan2(lr tan(delta), lf + lr), lf + lr > 0: reference cbf/cbf.py:175
+}
+
+template <typename T>
+__device__ inline void load_ego_(const KArgs<T>& p, long long qp, bool qp_only, Ego<T>& e,
+                                 T& ur0, T& ur1, int& bad)
+{
+    using v4 = typename VT<T>::v4;
+    using v2 = typename VT<T>::v2;
+    const v2 ur = reinterpret_cast<const v2*>(p.u_ref)[qp];
+    v4 s = v4{T(0), T(0), T(0), T(0)};
+    if (!qp_only) s = reinterpret_cast<const v4*>(p.state)[qp];
+    make_ego_(p, s, ur, qp_only, e, ur0, ur1, bad);
+}
+
+// The filter's answer in the caller's coordinates from the optimum w of the QP.
+template <typename T>
+__device__ inline typename VT<T>::v2 result_u_(const KArgs<T>& p, bool qp_only, int st, T w0, T w1,
+                                               const Ego<T>& e, T ur0, T ur1)
+{
+    using v2 = typename VT<T>::v2;
+    v2 out;
+    if (st != SCCBF_STATUS_OPTIMAL) {
+        out.x = ur0;
+        out.y = ur1;
+    } else {
+        // u = u_nom + Lc^-T w
+        T y1 = w1 * p.inv_l11;
+        T y0 = (w0 - p.l10 * y1) * p.inv_l00;
+        T u0 = e.un0 + y0, u1 = e.un1 + y1;
+        out.x = u0;
+        if (qp_only || (p.flags & SCCBF_FLAG_SLIP_IO))
+            out.y = u1;
+        else if (p.dynamics == SCCBF_DYN_KBM)
+            out.y = atan2_(u1 * p.L, ur0);                    // reference cbf/cbf.py:109
+        else
+            out.y = atan_(tan_(u1) * p.k_out);  // atan2((lf + lr) tan(beta), lr), lr > 0: reference cbf/cbf.py:216
+    }
+    return out;
+}
+
+template <typename T>
+__device__ inline void store_result_(const KArgs<T>& p, long long qp, bool qp_only, int st,
+                                     T w0, T w1, const Ego<T>& e, T ur0, T ur1)
+{
+    using v2 = typename VT<T>::v2;
+    reinterpret_cast<v2*>(p.u_out)[qp] = result_u_(p, qp_only, st, w0, w1, e, ur0, ur1);
+    p.status[qp] = st;
+}
+
+}  // namespace
