@@ -122,8 +122,10 @@ def test_solve_matches_oracle(oracle, name, dtype, lanes):
     uo, so, ro = _orc_solve(oracle, w)
     ug, sg, rg = _gpu_solve(w, dtype, lanes)
     _check(ug, sg, uo, so, ro, w["u_ref"], dtype)
-    tol = 1e-9 if dtype == torch.float64 else 5e-2
-    assert (np.abs(rg - ro) / (np.abs(ro) + 1e-3)).max() <= tol
+    # rows: every element against the magnitude of its row (h and b come out of cancelling terms as
+    # large as the row's normal, so their error scales with the row, not with themselves)
+    tol = 1e-9 if dtype == torch.float64 else 1e-3
+    assert (np.abs(rg - ro) / (np.abs(ro).max(axis=2, keepdims=True) + 1.0)).max() <= tol
 
 
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
