@@ -1,0 +1,59 @@
+"""What the compiler made of the bench's kernel, checked on the gfx950 assembly (no GPU needed).
+
+The kernel's overlap of loads and arithmetic rests on the compiler's counted `s_waitcnt vmcnt(N)`
+waits (loads issued in consumption order, every row waiting only for its own slots); a load in a
+conditional path, or another order of the loads, silently turns them into vmcnt(0).  Register and
+scratch use decide how many wavefronts fit on a SIMD.  One hipcc -S of the library, about a minute."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+from sccav_cbf_amd import _build
+
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+@pytest.fixture(scope="module")
+def asm(tmp_path_factory):
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not available")
+    out = tmp_path_factory.mktemp("isa") / "sccbf.s"
+    flags = [f for f in _build.HIPCC_FLAGS if f not in ("-shared", "-fPIC")]
+    cmd = [HIPCC] + flags + ["--cuda-device-only", "-S", "-I" + os.path.dirname(_build.HDR), "-o", str(out), _build.SRC]
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert res.returncode == 0, res.stdout[-2000:]
+    return out.read_text()
+
+
+def _kernel(asm, mangled_prefix):
+    m = re.search(r"^(%s\w*):[^\n]*\n(.*?)s_endpgm" % mangled_prefix, asm, flags=re.S | re.M)
+    assert m, "kernel %s not found" % mangled_prefix
+    meta = re.search(r"\.amdhsa_kernel %s\n(.*?)\.end_amdhsa_kernel" % re.escape(m.group(1)), asm, flags=re.S)
+    assert meta
+    return m.group(2), meta.group(1)
+
+
+def _meta(meta, key):
+    return int(re.search(r"\.amdhsa_%s (\d+)" % key, meta).group(1))
+
+
+def test_bench_kernel_keeps_counted_waits_and_fits_seven_waves(asm):
+    # k_group<float, 4, 4, false, false>: 4 lanes per QP, 4 rows per lane: 2 + 4 * 3 = 14 loads per lane
+    body, meta = _kernel(asm, "_ZN12_GLOBAL__N_17k_groupIfLi4ELi4ELb0ELb0EEEv")
+    waits = [int(n) for n in re.findall(r"s_waitcnt vmcnt\((\d+)\)", body)]
+    assert max(waits) >= 12, waits                    # the ego arithmetic starts with 12-13 loads still in flight
+    assert len(set(waits)) >= 12, sorted(set(waits))  # and every later row waits for its own loads only
+    assert _meta(meta, "private_segment_fixed_size") == 0          # no scratch
+    assert _meta(meta, "next_free_vgpr") <= 72                     # 7 wavefronts per SIMD
+    assert _meta(meta, "user_sgpr_kernarg_preload_length") >= 12   # leading arguments preloaded
+    assert 12000 <= _meta(meta, "group_segment_fixed_size") <= 14000   # the row table: 3 x 64 x 17 floats
+
+
+def test_other_variants_have_no_scratch(asm):
+    for name in ("_ZN12_GLOBAL__N_17k_groupIfLi1ELi16ELb0ELb0EEEv", "_ZN12_GLOBAL__N_17k_groupIfLi16ELi1ELb0ELb0EEEv",
+                 "_ZN12_GLOBAL__N_17k_groupIdLi4ELi4ELb0ELb0EEEv", "_ZN12_GLOBAL__N_19k_nominalIfEEv"):
+        _, meta = _kernel(asm, name)
+        assert _meta(meta, "private_segment_fixed_size") == 0, name
