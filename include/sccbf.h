@@ -234,19 +234,33 @@ int sccbf_vehicle_step_f64(int64_t A, double* state, const double* u, double lr,
 #define SCCBF_MOTION_CONSTANT_VELOCITY 1 /* per tick: ellipse centre += (vx, vy) dt; cone centre
                                             += v_o (cos, sin)(theta_o + beta) dt; radial centre
                                             += (cdot_x, cdot_y) dt; lanes stay */
+#define SCCBF_MOTION_SEEKER 2            /* ObstacleSpawner.update_seekers, reference
+                                            test_scripts/radial_dynamic_obstacles.py:193-239: after
+                                            the vehicle step every ellipse and radial slot turns
+                                            toward the agent's new position, yaw = atan2(y - cy,
+                                            x - cx), takes the speed max(seek_gain * distance,
+                                            seek_v_min) along that yaw (ellipse: theta_o = yaw too,
+                                            obstacles.py:288-292) and moves by velocity * dt; cones
+                                            keep their constant velocity, lanes stay */
 typedef struct sccbf_rollout_params {
     double max_steer; /* steering clip of the vehicle step [rad] */
     double dt;        /* tick length [s] */
     int32_t ticks;
     int32_t motion;   /* SCCBF_MOTION_* */
+    double seek_gain;  /* SCCBF_MOTION_SEEKER: speed per metre of distance [1/s] */
+    double seek_v_min; /* SCCBF_MOTION_SEEKER: least speed [m/s] */
 } sccbf_rollout_params;
 
-/* max_steer 30 deg, dt 0.1 (stanley_controller_ellipse.py:54,58), 0 ticks, static obstacles */
+/* max_steer 30 deg, dt 0.1 (stanley_controller_ellipse.py:54,58), 0 ticks, static obstacles,
+ * seek_gain 0.2, seek_v_min 3.0 (radial_dynamic_obstacles.py:193) */
 void sccbf_default_rollout_params(sccbf_rollout_params* p);
 
 /*
  *   state        T[A][4]   in: initial states; out: states after the last tick
- *   traj         T[N][4]   course, 1 <= N <= 2048 way-points (SCCBF_ERR_ROWS beyond)
+ *   traj         T[N][4]   course, 1 <= N <= 2048 way-points (SCCBF_ERR_ROWS beyond).  N = 0
+ *                          (traj, target_idx, pid_state then unused, may be NULL): no course, the
+ *                          nominal input is (0, 0) on every tick, as for the stationary ego of
+ *                          radial_dynamic_obstacles.py:444
  *   target_idx   i32[A]    in/out, as in sccbf_nominal_*
  *   pid_state    T[A][2]   in/out or NULL, as in sccbf_nominal_*
  *   obs, obs_type          as in sccbf_solve_* (planes or tiles; not the shared table), 1 <= M <= 64;

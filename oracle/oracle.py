@@ -193,3 +193,31 @@ def vehicle_step_batch(state, u, lr, lf, max_steer, dt):
     beta = np.empty(state.shape[0])
     lib().orc_vehicle_step_batch(state.shape[0], _dp(state), _dp(u), lr, lf, max_steer, dt, _dp(beta))
     return beta
+
+
+def seeker_step(obs, obs_type, ego_xy, dt, k=0.2, v_min=3.0):
+    """ObstacleSpawner.update_seekers, reference test_scripts/radial_dynamic_obstacles.py:210-234,
+    for every ellipse and radial slot of obs (M,2,A,4) float64, in place, in the reference's order:
+    yaw = arctan2(ego - centre) (217; the ellipse's theta becomes yaw, obstacles.py:288-292),
+    speed max(k * distance, v_min) (222-225), velocity = speed (cos yaw, sin yaw)
+    (obstacles.py:272-277), centre += velocity dt (233-234).  Cones move with their constant
+    velocity along theta_o + beta, lanes stay.  ego_xy (A,2) is the ego position after its step
+    (radial_dynamic_obstacles.py:481-487)."""
+    assert obs.dtype == np.float64
+    ego_xy = _f64(ego_xy)
+    for m, kind in enumerate(np.asarray(obs_type).tolist()):
+        if kind in (OBS_ELLIPSE, OBS_RADIAL):
+            cx, cy = obs[m, 0, :, 0], obs[m, 0, :, 1]
+            yaw = np.arctan2(ego_xy[:, 1] - cy, ego_xy[:, 0] - cx)
+            v = np.maximum(k * np.hypot(ego_xy[:, 0] - cx, ego_xy[:, 1] - cy), v_min)
+            vx, vy = v * np.cos(yaw), v * np.sin(yaw)
+            if kind == OBS_ELLIPSE:
+                obs[m, 1, :, 0], obs[m, 1, :, 1], obs[m, 1, :, 2] = yaw, vx, vy
+            else:
+                obs[m, 1, :, 0], obs[m, 1, :, 1] = vx, vy
+            cx += vx * dt
+            cy += vy * dt
+        elif kind == OBS_CONE:
+            ang = obs[m, 0, :, 2] + obs[m, 1, :, 1]
+            obs[m, 0, :, 0] += obs[m, 0, :, 3] * np.cos(ang) * dt
+            obs[m, 0, :, 1] += obs[m, 0, :, 3] * np.sin(ang) * dt

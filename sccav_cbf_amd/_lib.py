@@ -19,7 +19,7 @@ EXPORTS = ("sccbf_version", "sccbf_strerror", "sccbf_default_params", "sccbf_sol
            "sccbf_partials_f64", "sccbf_default_nominal_params", "sccbf_nominal_f32",
            "sccbf_nominal_f64", "sccbf_vehicle_step_f32", "sccbf_vehicle_step_f64",
            "sccbf_default_rollout_params", "sccbf_rollout_f32", "sccbf_rollout_f64")
-MOTION_STATIC, MOTION_CONSTANT_VELOCITY = 0, 1
+MOTION_STATIC, MOTION_CONSTANT_VELOCITY, MOTION_SEEKER = 0, 1, 2
 NOMINAL_WAYPOINT_SPEED = 1
 
 
@@ -39,7 +39,8 @@ class NominalParams(C.Structure):
 
 class RolloutParams(C.Structure):
     """struct sccbf_rollout_params of include/sccbf.h."""
-    _fields_ = [("max_steer", C.c_double), ("dt", C.c_double), ("ticks", C.c_int32), ("motion", C.c_int32)]
+    _fields_ = [("max_steer", C.c_double), ("dt", C.c_double), ("ticks", C.c_int32), ("motion", C.c_int32),
+                ("seek_gain", C.c_double), ("seek_v_min", C.c_double)]
 
 
 class SccbfError(RuntimeError):

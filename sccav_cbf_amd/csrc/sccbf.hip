@@ -263,21 +263,27 @@ int rollout_impl(const sccbf_params* sp, const sccbf_nominal_params* np, const s
     int rc = fill_args<T>(sp, A, M, r.f);
     if (rc != SCCBF_OK) return rc;
     if (N > kTrajChunk || M > 16 * kNomLanes) return SCCBF_ERR_ROWS;
-    if (N < 1 || M < 1 || rp->ticks < 0 || !(rp->dt > 0.0) || !(rp->max_steer >= 0.0)) return SCCBF_ERR_ARG;
-    if (rp->motion != SCCBF_MOTION_STATIC && rp->motion != SCCBF_MOTION_CONSTANT_VELOCITY) return SCCBF_ERR_ARG;
+    if (N < 0 || M < 1 || rp->ticks < 0 || !(rp->dt > 0.0) || !(rp->max_steer >= 0.0)) return SCCBF_ERR_ARG;
+    if (rp->motion != SCCBF_MOTION_STATIC && rp->motion != SCCBF_MOTION_CONSTANT_VELOCITY &&
+        rp->motion != SCCBF_MOTION_SEEKER)
+        return SCCBF_ERR_ARG;
+    if (rp->motion == SCCBF_MOTION_SEEKER && !(rp->seek_gain >= 0.0 && rp->seek_v_min >= 0.0)) return SCCBF_ERR_ARG;
     if (sp->dynamics != SCCBF_DYN_DBM) return SCCBF_ERR_ARG;  // update_com is the DBM step
     if (sp->flags & SCCBF_FLAG_OBS_SHARED) return SCCBF_ERR_ARG;  // moving obstacles are per agent
     if (A == 0 || rp->ticks == 0) return SCCBF_OK;
-    if (!state || !traj || !target_idx || !obs || !obs_type) return SCCBF_ERR_ARG;
+    if (!state || !obs || !obs_type) return SCCBF_ERR_ARG;
+    if (N > 0 && (!traj || !target_idx)) return SCCBF_ERR_ARG;
+    if (N == 0) pid_state = nullptr;
     if (pid_state && !(np->dt > 0.0)) return SCCBF_ERR_ARG;
     fill_nominal_args<T>(np, A, N, r.n);
     r.f.state = state; r.f.u_ref = nullptr; r.f.obs = obs; r.f.obs_type = obs_type;
     r.f.u_out = nullptr; r.f.status = nullptr; r.f.rows_out = nullptr;
     r.n.state = state; r.n.traj = traj; r.n.target_idx = target_idx; r.n.pid_state = pid_state;
-    r.n.u_ref = state;  // placeholder for the loader's nominal-input read (overwritten every tick)
+    r.n.u_ref = nullptr;
     r.state = state;
     r.k_in = (T)(sp->lr / (sp->lf + sp->lr)); r.inv_lr = (T)(1.0 / sp->lr);
     r.max_steer = (T)rp->max_steer; r.dt = (T)rp->dt;
+    r.seek_gain = (T)rp->seek_gain; r.seek_v_min = (T)rp->seek_v_min;
     r.ticks = rp->ticks; r.motion = rp->motion;
     r.h_min = h_min; r.n_active = n_active; r.n_infeasible = n_infeasible; r.trace = trace;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -408,6 +414,8 @@ void sccbf_default_rollout_params(sccbf_rollout_params* p)
     p->dt = 0.1;
     p->ticks = 0;
     p->motion = SCCBF_MOTION_STATIC;
+    p->seek_gain = 0.2;
+    p->seek_v_min = 3.0;
 }
 
 int sccbf_rollout_f32(const sccbf_params* p, const sccbf_nominal_params* np, const sccbf_rollout_params* rp,

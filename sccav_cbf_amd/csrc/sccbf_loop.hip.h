@@ -247,6 +247,7 @@ template <typename T> struct RArgs {
     NArgs<T> n;   // nominal: parameters, traj, N, target_idx (in/out), pid_state (in/out)
     T* state;     // [A][4] in/out
     T k_in, inv_lr, max_steer, dt;
+    T seek_gain, seek_v_min;
     int ticks;
     int motion;   // SCCBF_MOTION_*
     T* h_min;     // [A] optional
@@ -272,6 +273,34 @@ __device__ inline void advance_slot_(int type, typename VT<T>::v4& oa, typename 
         oa.x += ob.x * dt;
         oa.y += ob.y * dt;
     }
+}
+
+// seeker law, reference test_scripts/radial_dynamic_obstacles.py:210-234: turn toward the ego at
+// (x, y), speed max(gain * distance, v_min) along the new yaw, then move.  cos/sin of
+// atan2(dy, dx) are dx/d and dy/d; atan2(0, 0) = 0 gives the direction (1, 0).
+template <typename T>
+__device__ inline void seek_slot_(int type, typename VT<T>::v4& oa, typename VT<T>::v4& ob, T x, T y, T gain,
+                                  T v_min, T dt)
+{
+    if (type != SCCBF_OBS_ELLIPSE && type != SCCBF_OBS_RADIAL) {
+        advance_slot_<T>(type, oa, ob, dt);
+        return;
+    }
+    const T dx = x - oa.x, dy = y - oa.y;
+    const T d2 = dx * dx + dy * dy;
+    const T inv = d2 > T(0) ? rsqrt_(d2) : T(0);
+    const T v = max_(gain * (d2 * inv), v_min);
+    const T vx = d2 > T(0) ? v * dx * inv : v, vy = v * dy * inv;
+    if (type == SCCBF_OBS_ELLIPSE) {
+        ob.x = atan2_(dy, dx);
+        ob.y = vx;
+        ob.z = vy;
+    } else {
+        ob.x = vx;
+        ob.y = vy;
+    }
+    oa.x += vx * dt;
+    oa.y += vy * dt;
 }
 
 // `ticks` control ticks of nominal controller -> filter -> vehicle step (-> obstacle motion)
@@ -301,7 +330,8 @@ void k_rollout(const RArgs<T> a)
     const int qslot = (int)(threadIdx.x / G) * kMpad;
     const v4* traj4 = reinterpret_cast<const v4*>(np.traj);
 
-    stage_course_<T, kBlock>(c, traj4, 0, np.N);
+    const bool course = np.N > 0;  // else the nominal input is zero
+    if (course) stage_course_<T, kBlock>(c, traj4, 0, np.N);
     for (int i = threadIdx.x; i < np.N; i += kBlock) s_yaw[i] = traj4[i].z;
 
     // this lane's obstacle slots (r G + g) and everything the agent carries from tick to tick
@@ -309,13 +339,13 @@ void k_rollout(const RArgs<T> a)
     {
         KArgs<T> q = p;
         q.state = a.state;
-        q.u_ref = np.u_ref;  // any readable (A, 2) array: overwritten below before use
+        q.u_ref = a.state;  // any readable (A, 2) array: overwritten below before use
         group_load_<T, RPL, false, false>(q, ag, g, G, L);
     }
     v4 st = L.sv;
-    int tgt = np.target_idx[ag];
+    int tgt = course ? np.target_idx[ag] : 0;
     v2 ps = v2{T(0), T(0)};
-    if (np.pid_state) ps = reinterpret_cast<v2*>(np.pid_state)[ag];
+    if (course && np.pid_state) ps = reinterpret_cast<v2*>(np.pid_state)[ag];
     T h_min = INFINITY;
     int n_act = 0, n_inf = 0;
     __syncthreads();
@@ -323,6 +353,8 @@ void k_rollout(const RArgs<T> a)
 
     for (int tick = 0; tick < a.ticks; ++tick) {
         // nominal input
+        T acc = T(0), delta = T(0);
+        if (course) {
         T sth, cth;
         sincos_(st.z, &sth, &cth);
         const T fx = st.x + np.axle * cth, fy = st.y + np.axle * sth;
@@ -337,10 +369,10 @@ void k_rollout(const RArgs<T> a)
         const int ti = min(tgt, np.N - 1);
         T v_des = np.target_speed;
         if (np.flags & SCCBF_NOMINAL_WAYPOINT_SPEED) v_des = traj4[ti].w;
-        T acc, delta;
         stanley_pid_(np, st.z, st.w, sth, cth, fx, fy, c.x[(bi / kSub) * kSubStride + bi % kSub],
                      c.y[(bi / kSub) * kSubStride + bi % kSub], s_yaw[ti], v_des, np.pid_state != nullptr, ps,
                      acc, delta);
+        }
         // filter
         L.sv = st;
         L.urv = v2{acc, delta};
@@ -373,12 +405,16 @@ void k_rollout(const RArgs<T> a)
         if (a.motion == SCCBF_MOTION_CONSTANT_VELOCITY) {
 #pragma unroll
             for (int r = 0; r < RPL; ++r) advance_slot_<T>(L.ty[r], L.oa[r], L.ob[r], a.dt);
+        } else if (a.motion == SCCBF_MOTION_SEEKER) {
+#pragma unroll
+            for (int r = 0; r < RPL; ++r)
+                seek_slot_<T>(L.ty[r], L.oa[r], L.ob[r], st.x, st.y, a.seek_gain, a.seek_v_min, a.dt);
         }
     }
     if (live && g == 0) {
         reinterpret_cast<v4*>(a.state)[ag] = st;
-        np.target_idx[ag] = tgt;
-        if (np.pid_state) reinterpret_cast<v2*>(np.pid_state)[ag] = ps;
+        if (course) np.target_idx[ag] = tgt;
+        if (course && np.pid_state) reinterpret_cast<v2*>(np.pid_state)[ag] = ps;
         if (a.h_min) a.h_min[ag] = h_min;
         if (a.n_active) a.n_active[ag] = n_act;
         if (a.n_infeasible) a.n_infeasible[ag] = n_inf;

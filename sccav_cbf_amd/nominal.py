@@ -100,7 +100,10 @@ class ClosedLoop:
 
     tick() launches three kernels on the current stream and allocates nothing, so a caller may
     capture a number of ticks in a hipGraph.  Obstacles are whatever `obs` holds when the tick
-    runs: move them between ticks (or inside the captured region) with ordinary tensor ops."""
+    runs: move them between ticks (or inside the captured region) with ordinary tensor ops.
+
+    nominal=None, traj=None: no course, the nominal input is (0, 0) on every tick (the stationary
+    ego of test_scripts/radial_dynamic_obstacles.py:444)."""
 
     def __init__(self, cbf: BatchedCBF, nominal: BatchedNominal, traj, state, obs, obs_type,
                  max_steer=np.radians(30.0), dt=0.1, use_pid_state=False):
@@ -110,14 +113,17 @@ class ClosedLoop:
         A, dev, ty = state.shape[0], state.device, state.dtype
         self.target_idx = torch.zeros((A,), dtype=torch.int32, device=dev)
         self.pid_state = torch.zeros((A, 2), dtype=ty, device=dev) if use_pid_state else None
-        self.u_ref = torch.empty((A, 2), dtype=ty, device=dev)
+        if (nominal is None) != (traj is None):
+            raise ValueError("give both a nominal controller and a course, or neither")
+        self.u_ref = torch.zeros((A, 2), dtype=ty, device=dev)
         self.u = torch.empty((A, 2), dtype=ty, device=dev)
         self.status = torch.empty((A,), dtype=torch.int32, device=dev)
         self.beta = torch.empty((A,), dtype=ty, device=dev)
 
-    def rollout(self, ticks, motion="static", trace=False):
+    def rollout(self, ticks, motion="static", trace=False, seek_gain=0.2, seek_v_min=3.0):
         """`ticks` ticks in ONE launch (sccbf_rollout_*): state, target_idx and pid_state advance in
-        place; obstacles may move with constant velocity inside the launch (`obs` itself is not written).
+        place; obstacles may move inside the launch, with constant velocity or as seekers of
+        radial_dynamic_obstacles.py:193-239 (`obs` itself is not written).
         Returns a dict: h_min (A,), n_active (A,), n_infeasible (A,) and, if asked for,
         trace (ticks, A, 4) = a*, delta*, beta, status per tick."""
         A, dev, ty = self.state.shape[0], self.state.device, self.state.dtype
@@ -134,12 +140,15 @@ class ClosedLoop:
             flags |= _lib.FLAG_TYPE_PER_AGENT
         if self.cbf.slip_io:
             raise ValueError("rollout works in the caller's coordinates (a, delta): slip_io must be off")
-        N = self.traj.shape[0]
+        N = 0 if self.traj is None else self.traj.shape[0]
         rp = _lib.RolloutParams()
         lib = _lib.load()
         lib.sccbf_default_rollout_params(C.byref(rp))
         rp.max_steer, rp.dt, rp.ticks = self.max_steer, self.dt, int(ticks)
-        rp.motion = {"static": _lib.MOTION_STATIC, "constant_velocity": _lib.MOTION_CONSTANT_VELOCITY}[motion]
+        rp.motion = {"static": _lib.MOTION_STATIC, "constant_velocity": _lib.MOTION_CONSTANT_VELOCITY,
+                     "seeker": _lib.MOTION_SEEKER}[motion]
+        rp.seek_gain, rp.seek_v_min = float(seek_gain), float(seek_v_min)
+        nominal_params = self.nominal.params if self.nominal is not None else _lib.NominalParams()
         out = dict(h_min=torch.empty((A,), dtype=ty, device=dev),
                    n_active=torch.empty((A,), dtype=torch.int32, device=dev),
                    n_infeasible=torch.empty((A,), dtype=torch.int32, device=dev))
@@ -149,7 +158,7 @@ class ClosedLoop:
         fn = lib.sccbf_rollout_f32 if ty == torch.float32 else lib.sccbf_rollout_f64
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
-            rc = fn(C.byref(self.cbf.params), C.byref(self.nominal.params), C.byref(rp), A, M, N,
+            rc = fn(C.byref(self.cbf.params), C.byref(nominal_params), C.byref(rp), A, M, N,
                     _ptr(self.state), _ptr(self.traj), _ptr(self.target_idx), _ptr(self.pid_state), _ptr(obs),
                     _ptr(self.obs_type), _ptr(out["h_min"]), _ptr(out["n_active"]), _ptr(out["n_infeasible"]),
                     _ptr(out.get("trace")), C.c_void_p(stream))
@@ -157,7 +166,8 @@ class ClosedLoop:
         return out
 
     def tick(self):
-        self.nominal.control(self.state, self.traj, self.target_idx, self.pid_state, u_ref=self.u_ref)
+        if self.nominal is not None:
+            self.nominal.control(self.state, self.traj, self.target_idx, self.pid_state, u_ref=self.u_ref)
         self.cbf.solve(self.state, self.u_ref, self.obs, self.obs_type, u_out=self.u, status=self.status)
         vehicle_step(self.state, self.u, lr=self.cbf.params.lr, lf=self.cbf.params.lf,
                      max_steer=self.max_steer, dt=self.dt, beta_out=self.beta)

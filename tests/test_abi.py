@@ -90,10 +90,11 @@ def test_nominal_and_vehicle_step_argument_validation(lib):
 
 
 def test_rollout_argument_validation(lib):
-    assert C.sizeof(_lib.RolloutParams) == 2 * 8 + 2 * 4
+    assert C.sizeof(_lib.RolloutParams) == 2 * 8 + 2 * 4 + 2 * 8
     r = _lib.RolloutParams()
     lib.sccbf_default_rollout_params(C.byref(r))
     assert abs(r.max_steer - 0.5235987755982988) < 1e-15 and r.dt == 0.1 and (r.ticks, r.motion) == (0, 0)
+    assert (r.seek_gain, r.seek_v_min) == (0.2, 3.0)      # radial_dynamic_obstacles.py:193
     p, q = _lib.Params(), _lib.NominalParams()
     lib.sccbf_default_params(C.byref(p))
     lib.sccbf_default_nominal_params(C.byref(q))
@@ -104,10 +105,13 @@ def test_rollout_argument_validation(lib):
     assert call(8, 4, 100) == -1                     # null data
     assert call(8, 4, 2049) == -2                    # course longer than one LDS pass
     assert call(8, 65, 100) == -2                    # more slots than four lanes hold
-    assert call(8, 0, 100) == -1 and call(8, 4, 0) == -1
+    assert call(8, 0, 100) == -1 and call(8, 4, -1) == -1
+    assert call(0, 4, 0) == 0                        # no course: the nominal input is zero
     r.motion = 9
     assert call(8, 4, 100) == -1
-    r.motion = 0
+    r.motion, r.seek_gain = 2, -1.0
+    assert call(8, 4, 100) == -1                     # seeker law needs gains >= 0
+    r.motion, r.seek_gain = 0, 0.2
     p.dynamics = 1
     assert call(8, 4, 100) == -1                     # the vehicle step is the DBM one
     p.dynamics = 0

@@ -271,3 +271,81 @@ def test_c1_by_one_rollout_launch():
     assert np.abs(beta_deg - ref).max() <= 1e-3
     assert int(out["n_active"][0]) == 59 and int(out["n_infeasible"][0]) == 0      # ticks with an active row
     assert float(out["h_min"][0]) > -1e-6                                          # the barrier is never crossed
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
+def test_rollout_seekers_equal_tick_by_tick(oracle, dtype):
+    """SCCBF_MOTION_SEEKER inside the launch against nominal -> filter -> vehicle step launched tick
+    by tick with the oracle's seeker step (radial_dynamic_obstacles.py:193-239) moving the obstacles
+    on the host between ticks: ellipse and radial slots seek, cones drift."""
+    from sccav_cbf_amd.nominal import vehicle_step
+    A, M, T = 200, 12, 20
+    make = _rollout_case(A, M, 77, dtype, False)
+    la, obs_a, ty = make()
+    ty_np = ty.cpu().numpy().copy()
+    ty_np[0:3] = _lib.OBS_RADIAL          # ellipse slots read as radial ones: cx, cy, a, b, cdot, kv
+    obs_np = obs_a.double().cpu().numpy().copy()
+    obs_np[0:3, 1, :, 2] = 1.0            # kv
+    ty = torch.from_numpy(ty_np).to(DEV)
+
+    def fresh():
+        loop, _, _ = make()
+        loop.obs = torch.from_numpy(obs_np).to(DEV).to(dtype)
+        loop.obs_type = ty
+        return loop
+    la = fresh()
+    host = obs_np.copy()
+    tr = []
+    for _ in range(T):
+        la.nominal.control(la.state, la.traj, la.target_idx, la.pid_state, u_ref=la.u_ref)
+        u, st = la.cbf.solve(la.state, la.u_ref, la.obs, ty, u_out=la.u, status=la.status)
+        vehicle_step(la.state, la.u, lr=1.45, lf=1.45, max_steer=la.max_steer, dt=la.dt, beta_out=la.beta)
+        tr.append(torch.cat([u, la.beta[:, None], st.to(dtype)[:, None]], dim=1).clone())
+        oracle.seeker_step(host, ty_np, la.state[:, 0:2].double().cpu().numpy(), la.dt, k=0.3, v_min=2.0)
+        la.obs = torch.from_numpy(host).to(DEV).to(dtype)
+    tr = torch.stack(tr)
+    lb = fresh()
+    out = lb.rollout(T, motion="seeker", trace=True, seek_gain=0.3, seek_v_min=2.0)
+    torch.cuda.synchronize()
+    tol = 1e-7 if dtype == torch.float64 else 5e-3
+    same = (out["trace"][:, :, 3] == tr[:, :, 3]).all(dim=0)
+    # fp64: seekers crowd the agents, and one whose rows close to a sliver is driven to |a| ~ 1e5
+    # and speeds ~ 1e5 m/s, where the feasibility decision is a coin toss between the two runs
+    assert same.float().mean().item() >= (0.99 if dtype == torch.float64 else 0.97)
+    scale = 1 + tr[:, :, :2].abs().amax(dim=(0, 2))
+    d = ((out["trace"][:, :, :3] - tr[:, :, :3]).abs().amax(dim=(0, 2)) / scale)[same].max().item()
+    assert d <= tol, d
+    assert ((lb.state - la.state).abs().amax(dim=1) / scale)[same].max().item() <= tol * 50
+
+
+def test_radial_seeker_scenario_by_one_rollout_launch(oracle):
+    """The radial scenario (ego at rest, nominal input (0, 0), 32 circular seekers closing in;
+    radial_dynamic_obstacles.py:427-487) for 16 egos in ONE launch without a course, fp64, against
+    the same loop done entirely by the oracle on the host."""
+    from sccav_cbf_amd import scenarios
+    from sccav_cbf_amd.batched import BatchedCBF
+    from sccav_cbf_amd.nominal import ClosedLoop
+    A, M, T, dt = 16, 32, 90, 1.0 / 30.0
+    w = scenarios.radial_seekers(M=M, A=A, seed=1236)
+    state = torch.from_numpy(w["state"]).to(DEV)
+    loop = ClosedLoop(BatchedCBF(alpha=1.0), None, None, state, torch.from_numpy(w["obs"]).to(DEV),
+                      torch.from_numpy(w["obs_type"]).to(DEV), dt=dt)
+    out = loop.rollout(T, motion="seeker", trace=True)
+    torch.cuda.synchronize()
+    prm = oracle.make_params(alpha=1.0)
+    s, obs = w["state"].copy(), w["obs"].copy()
+    zero = np.zeros((A, 2))
+    tr = np.empty((T, A, 4))
+    hmin = np.full(A, np.inf)
+    for t in range(T):
+        u, st, rows = oracle.solve_batch(prm, s, zero, obs, w["obs_type"], want_rows=True)
+        hmin = np.minimum(hmin, rows[:, :, 3].min(axis=0))
+        beta = oracle.vehicle_step_batch(s, u, 1.45, 1.45, np.radians(30.0), dt)
+        tr[t, :, 0:2], tr[t, :, 2], tr[t, :, 3] = u, beta, st
+        oracle.seeker_step(obs, w["obs_type"], s[:, 0:2], dt)
+    got = out["trace"].cpu().numpy()
+    assert np.array_equal(got[:, :, 3], tr[:, :, 3])
+    assert (tr[:, :, 3] == 0).any() and (np.abs(tr[:, :, 0]) > 1e-3).any()       # the filter did act
+    assert np.abs(got[:, :, :3] - tr[:, :, :3]).max() <= 1e-7 * (1 + np.abs(tr[:, :, :3]).max())
+    assert np.abs(loop.state.cpu().numpy() - s).max() <= 1e-7 * (1 + np.abs(s).max())
+    assert np.abs(out["h_min"].cpu().numpy() - hmin).max() <= 1e-7 * (1 + np.abs(hmin).max())

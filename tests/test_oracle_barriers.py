@@ -201,3 +201,20 @@ def test_kbm_row(oracle):
     row = oracle.row(p, s, d)
     assert abs(row[0] - (np.cos(0.6) * d["hx"] + np.sin(0.6) * d["hy"])) < 1e-12
     assert row[1] == d["hth"] and abs(row[2] + 2.0 * d["h"]) < 1e-12
+
+
+def test_seeker_step_known_answer(oracle):
+    """radial_dynamic_obstacles.py:210-234 by hand: obstacle at (3, 4), ego at the origin: distance 5,
+    speed max(0.2 * 5, 3) = 3 toward the ego, 0.1 s; a far one at (-30, 40) moves at 0.2 * 50 = 10."""
+    obs = np.zeros((3, 2, 2, 4))
+    obs[0, 0, :, 0:2] = [[3.0, 4.0], [-30.0, 40.0]]      # radial
+    obs[1, 0, :, 0:2] = [[3.0, 4.0], [-30.0, 40.0]]      # ellipse: theta_o follows the yaw
+    obs[2, 0, :, :] = [[1.0, 2.0, np.pi / 2, 5.0]] * 2   # cone: constant velocity along theta_o + beta
+    ty = np.array([oracle.OBS_RADIAL, oracle.OBS_ELLIPSE, oracle.OBS_CONE], dtype=np.uint8)
+    oracle.seeker_step(obs, ty, np.zeros((2, 2)), 0.1)
+    for m in (0, 1):
+        assert np.allclose(obs[m, 0, 0, 0:2], [3.0 - 0.18, 4.0 - 0.24], atol=1e-15)
+        assert np.allclose(obs[m, 0, 1, 0:2], [-30.0 + 0.6, 40.0 - 0.8], atol=1e-14)
+    assert np.allclose(obs[0, 1, 0, 0:2], [-1.8, -2.4], atol=1e-15)                    # cdot
+    assert np.allclose(obs[1, 1, 0, 0:3], [np.arctan2(-4.0, -3.0), -1.8, -2.4], atol=1e-15)
+    assert np.allclose(obs[2, 0, 0, 0:2], [1.0, 2.5], atol=1e-15)
