@@ -62,6 +62,13 @@ extern "C" {
 /* vehicle model */
 #define SCCBF_DYN_DBM 0 /* DBM_CBF_2DS,  reference cbf/cbf.py:112-220, u = [a, beta]  */
 #define SCCBF_DYN_KBM 1 /* KBM_VC_CBF2D, reference cbf/cbf.py:33-110,  u = [v, omega] */
+#define SCCBF_DYN_DUM 2 /* DUM_CBF_2DS, reference cbf/cbf.py:222-298, u = [a, omega]: g_c of 237-239
+                           (a drives v, omega drives yaw), drift [v cos, v sin, 0, 0]; as written the
+                           drift is declared 5x1 with four entries (243-245) and the class does not run:
+                           here with the 4x1 drift.  No steering transform (247-298 apply none).
+                           M <= 256 (SCCBF_ERR_ROWS beyond) */
+#define SCCBF_DYN_SADBM 3 /* SADBM_CBF_2DS, reference cbf/cbf.py:301-437: slip angle beta is a fifth
+                             state, u = [a, d(beta)/dt].  Only through sccbf_solve_sa_* */
 
 /* per-agent result */
 #define SCCBF_STATUS_OPTIMAL 0
@@ -78,6 +85,10 @@ extern "C" {
                                         tile one contiguous block of 128 M 4-vectors; the last tile
                                         may be partly unused but must be allocated in full; not
                                         combinable with SCCBF_FLAG_OBS_SHARED */
+#define SCCBF_FLAG_CONE_BETA_STATE 16u /* sccbf_solve_sa_* only: every cone slot takes beta from the
+                                          agent's slip state instead of its own o[5], which is what
+                                          the reference's cones hold after SADBM's first solve
+                                          (cbf.py:424-427) */
 
 /* error codes */
 #define SCCBF_OK 0
@@ -139,6 +150,32 @@ int sccbf_solve_f64(const sccbf_params* p, int64_t A, int32_t M,
                     const double* obs, const uint8_t* obs_type,
                     double* u_out, int32_t* status, double* rows_out,
                     void* stream);
+
+/*
+ * Steer-rate model: SADBM_CBF_2DS.solve_cbf, reference cbf/cbf.py:349-437, for A agents.
+ *   slip  T[A][2] in/out: beta (the fifth state, cbf.py:335,421) and the slip angle of the last
+ *         nominal input, beta_ref_last (cbf.py:334,369); zeros before the first tick
+ *   dt    the time step of this call [s] (cbf.py:332; the reference's dt=None mode measures wall
+ *         clock, 361-367: such a caller measures on the host and passes the value, >= zero_tol)
+ * Per agent: beta_ref = atan2(lr tan(delta_ref), lf + lr) (359), nominal input
+ * [a_ref, (beta_ref - beta_ref_last) / dt] (367-372), rows
+ *     [dh/dv, dh/dbeta] . u >= -(Lf_h + alpha h + dh/dt),
+ *     Lf_h = dh/dx v cos(yaw + beta) + dh/dy v sin(yaw + beta) + dh/dyaw v sin(beta) / lr   (338-347, 398-405)
+ * with dh/dbeta = dh/dyaw for a collision cone (obstacles.py:460-466) and 0 otherwise (124-125),
+ * the QP, then beta += beta_dot* dt (421) and u_out = [a*, atan2((lf + lr) tan(beta), lr)] (430).
+ * Status other than optimal: the nominal input is applied (beta += beta_dot_ref dt).
+ * Cone slots read their own beta o[5] unless SCCBF_FLAG_CONE_BETA_STATE is set.
+ * p->dynamics is ignored; SCCBF_FLAG_SLIP_IO is not allowed; 1 <= M <= 256 (an empty list raises
+ * in the reference, 375-378); rows_out as in sccbf_solve_*.
+ */
+int sccbf_solve_sa_f32(const sccbf_params* p, double dt, int64_t A, int32_t M,
+                       const float* state, float* slip, const float* u_ref,
+                       const float* obs, const uint8_t* obs_type,
+                       float* u_out, int32_t* status, float* rows_out, void* stream);
+int sccbf_solve_sa_f64(const sccbf_params* p, double dt, int64_t A, int32_t M,
+                       const double* state, double* slip, const double* u_ref,
+                       const double* obs, const uint8_t* obs_type,
+                       double* u_out, int32_t* status, double* rows_out, void* stream);
 
 /*
  * The QP stage alone, on caller-supplied rows: for each agent

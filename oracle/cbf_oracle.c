@@ -33,10 +33,13 @@
 
 #define ORC_DYN_DBM 0
 #define ORC_DYN_KBM 1
+#define ORC_DYN_DUM 2
+#define ORC_DYN_SADBM 3
 
 #define ORC_FLAG_OBS_SHARED 1u
 #define ORC_FLAG_TYPE_PER_AGENT 2u
 #define ORC_FLAG_SLIP_IO 4u
+#define ORC_FLAG_CONE_BETA_STATE 16u
 
 #define ORC_LANE_ITERS 32
 #define ORC_LANE_HALVINGS 30
@@ -200,7 +203,10 @@ int orc_barrier(int type, const double s[4], const double o[8], double zero_tol,
  *   Lg_h = [ h_v ,  v(-sin(th) h_x + cos(th) h_y) + (v/lr) h_th ]
  *   Lf_h = v (cos(th) h_x + sin(th) h_y),   b = -(Lf_h + alpha h + h_t)
  * KBM: g_c of cbf/cbf.py:94, rows 98-101 (no drift, no h_t):
- *   Lg_h = [ cos(th) h_x + sin(th) h_y ,  h_th ],   b = -alpha h          */
+ *   Lg_h = [ cos(th) h_x + sin(th) h_y ,  h_th ],   b = -alpha h
+ * DUM: g_c of cbf/cbf.py:237-239 (column lists: a -> v, omega -> yaw), drift 243-245 with its
+ * four entries (the declared 5x1 shape does not build), contraction 279-286:
+ *   Lg_h = [ h_v , h_th ],   Lf_h = v (cos(th) h_x + sin(th) h_y),   b as for DBM */
 void orc_row(const orc_params* p, const double s[4], const orc_partials* d, double row[3])
 {
     double ct = cos(s[2]), st = sin(s[2]), v = s[3];
@@ -208,12 +214,33 @@ void orc_row(const orc_params* p, const double s[4], const orc_partials* d, doub
         row[0] = ct * d->hx + st * d->hy;
         row[1] = d->hth;
         row[2] = -(p->alpha * d->h);
+    } else if (p->dynamics == ORC_DYN_DUM) {
+        row[0] = d->hv;
+        row[1] = d->hth;
+        double lf_h = v * (ct * d->hx + st * d->hy);
+        row[2] = -(lf_h + p->alpha * d->h + d->ht);
     } else {
         row[0] = d->hv;
         row[1] = v * (-st * d->hx + ct * d->hy) + (v / p->lr) * d->hth;
         double lf_h = v * (ct * d->hx + st * d->hy);
         row[2] = -(lf_h + p->alpha * d->h + d->ht);
     }
+}
+
+/* SADBM_CBF_2DS, cbf/cbf.py:338-347 (g_c, f_c) and 398-405: state x, y, yaw, v, beta;
+ *   Lg_h = [ h_v , h_beta ],
+ *   Lf_h = h_x v cos(yaw + beta) + h_y v sin(yaw + beta) + h_th v sin(beta) / lr
+ * h_beta: CollisionCone2D.dbeta = dtheta (cbf/obstacles.py:460-466), 0 for the other kinds
+ * (Obstacle2DBase.dbeta, obstacles.py:124-125). */
+void orc_row_sa(const orc_params* p, const double s[4], double beta, const orc_partials* d,
+                double h_beta, double row[3])
+{
+    double v = s[3];
+    double lf_h = d->hx * v * cos(s[2] + beta) + d->hy * v * sin(s[2] + beta) +
+                  d->hth * v * sin(beta) / p->lr;
+    row[0] = d->hv;
+    row[1] = h_beta;
+    row[2] = -(lf_h + p->alpha * d->h + d->ht);
 }
 
 /* ------------------------------------------------------------------- the QP */
@@ -405,7 +432,7 @@ int orc_solve_batch(const orc_params* p, int64_t A, int32_t M, const double* sta
                     orc_finite(ur0) && orc_finite(ur1));
         double u_nom[2];
         u_nom[0] = ur0;
-        if (p->flags & ORC_FLAG_SLIP_IO)
+        if ((p->flags & ORC_FLAG_SLIP_IO) || p->dynamics == ORC_DYN_DUM)
             u_nom[1] = ur1;
         else if (p->dynamics == ORC_DYN_KBM)
             u_nom[1] = ur0 * tan(ur1) / p->L;
@@ -442,7 +469,7 @@ int orc_solve_batch(const orc_params* p, int64_t A, int32_t M, const double* sta
         if (st != 0) {
             u_out[2 * a] = ur0;
             u_out[2 * a + 1] = ur1;
-        } else if (p->flags & ORC_FLAG_SLIP_IO) {
+        } else if ((p->flags & ORC_FLAG_SLIP_IO) || p->dynamics == ORC_DYN_DUM) {
             u_out[2 * a] = u[0];
             u_out[2 * a + 1] = u[1];
         } else if (p->dynamics == ORC_DYN_KBM) {
@@ -453,6 +480,76 @@ int orc_solve_batch(const orc_params* p, int64_t A, int32_t M, const double* sta
             u_out[2 * a + 1] = atan2((p->lf + p->lr) * tan(u[1]), p->lr);
         }
         status[a] = st;
+    }
+    return 0;
+}
+
+/*
+ * SADBM_CBF_2DS.solve_cbf, cbf/cbf.py:349-437, for A agents with a given time step (the
+ * reference's fixed-dt mode, 331-332).  slip is [A][2] in/out = beta, beta_ref_last.
+ * delta_ref -> beta_ref (359), beta_ref_dot (367), nominal input [a_ref, beta_ref_dot] (372),
+ * the QP, beta += beta_dot dt (421), delta = atan2((lf + lr) tan(beta), lr) (430).  When the QP
+ * has no answer the nominal input is integrated instead; non-finite data pass through.
+ * With ORC_FLAG_CONE_BETA_STATE the cones take the agent's beta (what cbf.py:424-427 leaves in
+ * them for the next call), else the beta of their slot.
+ */
+int orc_solve_sa_batch(const orc_params* p, double dt, int64_t A, int32_t M, const double* state,
+                       double* slip, const double* u_ref, const double* obs, const uint8_t* obs_type,
+                       double* u_out, int32_t* status, double* rows_out, int use_incremental)
+{
+    if (!p || A < 0 || M < 1 || M > 1024 || !(dt > 0.0)) return -1;
+    const int shared = (p->flags & ORC_FLAG_OBS_SHARED) != 0;
+    const int type_pa = (p->flags & ORC_FLAG_TYPE_PER_AGENT) != 0;
+#pragma omp parallel for schedule(static)
+    for (int64_t a = 0; a < A; ++a) {
+        double rows[3 * 1024];
+        double work[3 * 1024];
+        const double* s = state + 4 * a;
+        double ur0 = u_ref[2 * a], ur1 = u_ref[2 * a + 1];
+        double beta = slip[2 * a], beta_ref_last = slip[2 * a + 1];
+        int bad = !(orc_finite(s[0]) && orc_finite(s[1]) && orc_finite(s[2]) && orc_finite(s[3]) &&
+                    orc_finite(ur0) && orc_finite(ur1) && orc_finite(beta) && orc_finite(beta_ref_last));
+        double beta_ref = atan2(p->lr * tan(ur1), p->lf + p->lr);
+        double u_nom[2] = {ur0, (beta_ref - beta_ref_last) / dt};
+        for (int m = 0; m < M; ++m) {
+            double o[8];
+            for (int h = 0; h < 2; ++h)
+                for (int c = 0; c < 4; ++c)
+                    o[4 * h + c] = shared ? obs[((size_t)m * 2 + h) * 4 + c]
+                                          : obs[(((size_t)m * 2 + h) * A + a) * 4 + c];
+            int type = type_pa ? obs_type[(size_t)m * A + a] : obs_type[m];
+            if (type == ORC_OBS_CONE && (p->flags & ORC_FLAG_CONE_BETA_STATE)) o[5] = beta;
+            orc_partials d;
+            double* row = rows + 3 * m;
+            if (orc_barrier(type, s, o, p->zero_tol, &d)) {
+                orc_row_sa(p, s, beta, &d, type == ORC_OBS_CONE ? d.hth : 0.0, row);
+                if (!(orc_finite(row[0]) && orc_finite(row[1]) && orc_finite(row[2]))) bad = 1;
+            } else {
+                row[0] = 0.0; row[1] = 0.0; row[2] = -1.0;
+            }
+            if (rows_out) {
+                double* ro = rows_out + ((size_t)m * A + a) * 4;
+                ro[0] = row[0]; ro[1] = row[1]; ro[2] = row[2]; ro[3] = d.h;
+            }
+        }
+        double u[2] = {u_nom[0], u_nom[1]};
+        int st = 2;
+        if (!bad) {
+            st = use_incremental ? orc_qp2_incremental(M, rows, p->R, u_nom, u, work)
+                                 : orc_qp2_enum(M, rows, p->R, u_nom, u, work);
+            if (st != 0) { u[0] = u_nom[0]; u[1] = u_nom[1]; }
+        }
+        status[a] = st;
+        if (st == 2) {
+            u_out[2 * a] = ur0;
+            u_out[2 * a + 1] = ur1;
+            continue;
+        }
+        beta += u[1] * dt;
+        slip[2 * a] = beta;
+        slip[2 * a + 1] = beta_ref;
+        u_out[2 * a] = u[0];
+        u_out[2 * a + 1] = atan2((p->lf + p->lr) * tan(beta), p->lr);
     }
     return 0;
 }

@@ -14,8 +14,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "liboracle.so")
 
 OBS_ELLIPSE, OBS_CONE, OBS_LANE, OBS_RADIAL, OBS_EMPTY = 0, 1, 2, 3, 255
-DYN_DBM, DYN_KBM = 0, 1
+DYN_DBM, DYN_KBM, DYN_DUM, DYN_SADBM = 0, 1, 2, 3
 FLAG_OBS_SHARED, FLAG_TYPE_PER_AGENT, FLAG_SLIP_IO = 1, 2, 4
+FLAG_CONE_BETA_STATE = 16
 
 
 class Params(C.Structure):
@@ -61,6 +62,11 @@ def lib():
         L.orc_solve_batch.restype = C.c_int
         L.orc_solve_batch.argtypes = [C.POINTER(Params), C.c_int64, C.c_int32, dp, dp, dp,
                                       C.POINTER(C.c_uint8), dp, C.POINTER(C.c_int32), dp, C.c_int]
+        L.orc_solve_sa_batch.restype = C.c_int
+        L.orc_solve_sa_batch.argtypes = [C.POINTER(Params), C.c_double, C.c_int64, C.c_int32, dp, dp, dp, dp,
+                                         C.POINTER(C.c_uint8), dp, C.POINTER(C.c_int32), dp, C.c_int]
+        L.orc_row_sa.restype = None
+        L.orc_row_sa.argtypes = [C.POINTER(Params), dp, C.c_double, C.POINTER(Partials), C.c_double, dp]
         L.orc_qp_batch.restype = C.c_int
         L.orc_qp_batch.argtypes = [C.POINTER(Params), C.c_int64, C.c_int32, dp, dp, dp,
                                    C.POINTER(C.c_int32), C.c_int]
@@ -115,6 +121,36 @@ def solve_batch(params, state, u_ref, obs, obs_type, want_rows=False, incrementa
     if rc != 0:
         raise ValueError("orc_solve_batch failed: %d" % rc)
     return u_out, status, rows
+
+
+def solve_sa_batch(params, dt, state, slip, u_ref, obs, obs_type, want_rows=False, incremental=False):
+    """One tick of the steer-rate model (SADBM_CBF_2DS.solve_cbf, cbf/cbf.py:349-437) for A agents.
+    slip (A,2) float64 = beta, beta_ref_last is updated in place.  Returns u_out (A,2) = a*, delta*,
+    status (A,), rows (M,A,4) or None."""
+    state, u_ref, obs = _f64(state), _f64(u_ref), _f64(obs)
+    obs_type = np.ascontiguousarray(obs_type, dtype=np.uint8)
+    A, M = state.shape[0], obs.shape[0]
+    assert slip.dtype == np.float64 and slip.shape == (A, 2) and slip.flags.c_contiguous
+    assert obs.shape == ((M, 2, 4) if params.flags & FLAG_OBS_SHARED else (M, 2, A, 4))
+    assert obs_type.shape == ((M, A) if params.flags & FLAG_TYPE_PER_AGENT else (M,))
+    u_out = np.empty((A, 2))
+    status = np.empty(A, dtype=np.int32)
+    rows = np.empty((M, A, 4)) if want_rows else None
+    rc = lib().orc_solve_sa_batch(C.byref(params), float(dt), A, M, _dp(state), _dp(slip), _dp(u_ref), _dp(obs),
+                                  obs_type.ctypes.data_as(C.POINTER(C.c_uint8)), _dp(u_out),
+                                  status.ctypes.data_as(C.POINTER(C.c_int32)),
+                                  _dp(rows) if want_rows else None, int(incremental))
+    if rc != 0:
+        raise ValueError("orc_solve_sa_batch failed: %d" % rc)
+    return u_out, status, rows
+
+
+def row_sa(params, s, beta, partials, h_beta):
+    d = Partials(**partials)
+    s = _f64(s)
+    out = np.empty(3)
+    lib().orc_row_sa(C.byref(params), _dp(s), float(beta), C.byref(d), float(h_beta), _dp(out))
+    return out
 
 
 def qp_batch(params, rows, u_nom, incremental=False):

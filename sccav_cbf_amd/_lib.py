@@ -8,9 +8,10 @@ import os
 from ._build import LIB
 
 OBS_ELLIPSE, OBS_CONE, OBS_LANE, OBS_RADIAL, OBS_EMPTY = 0, 1, 2, 3, 255
-DYN_DBM, DYN_KBM = 0, 1
+DYN_DBM, DYN_KBM, DYN_DUM, DYN_SADBM = 0, 1, 2, 3
 STATUS_OPTIMAL, STATUS_INFEASIBLE, STATUS_NONFINITE = 0, 1, 2
 FLAG_OBS_SHARED, FLAG_TYPE_PER_AGENT, FLAG_SLIP_IO, FLAG_OBS_TILED = 1, 2, 4, 8
+FLAG_CONE_BETA_STATE = 16
 MAX_ROWS = 1024
 ERR_ARG, ERR_ROWS, ERR_WEIGHT, ERR_LAUNCH, ERR_VARIANT, ERR_NO_DEVICE = -1, -2, -3, -4, -5, -6
 
@@ -18,7 +19,8 @@ EXPORTS = ("sccbf_version", "sccbf_strerror", "sccbf_default_params", "sccbf_sol
            "sccbf_solve_f64", "sccbf_qp_f32", "sccbf_qp_f64", "sccbf_partials_f32",
            "sccbf_partials_f64", "sccbf_default_nominal_params", "sccbf_nominal_f32",
            "sccbf_nominal_f64", "sccbf_vehicle_step_f32", "sccbf_vehicle_step_f64",
-           "sccbf_default_rollout_params", "sccbf_rollout_f32", "sccbf_rollout_f64")
+           "sccbf_default_rollout_params", "sccbf_rollout_f32", "sccbf_rollout_f64",
+           "sccbf_solve_sa_f32", "sccbf_solve_sa_f64")
 MOTION_STATIC, MOTION_CONSTANT_VELOCITY, MOTION_SEEKER = 0, 1, 2
 NOMINAL_WAYPOINT_SPEED = 1
 
@@ -70,6 +72,10 @@ def load():
         f = getattr(L, name)
         f.restype = C.c_int
         f.argtypes = [C.POINTER(Params), C.c_int64, C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp]
+    for name in ("sccbf_solve_sa_f32", "sccbf_solve_sa_f64"):
+        f = getattr(L, name)
+        f.restype = C.c_int
+        f.argtypes = [C.POINTER(Params), C.c_double, C.c_int64, C.c_int32] + [vp] * 9
     for name in ("sccbf_qp_f32", "sccbf_qp_f64"):
         f = getattr(L, name)
         f.restype = C.c_int

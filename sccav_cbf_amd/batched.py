@@ -15,7 +15,8 @@ from ._lib import (DYN_DBM, DYN_KBM, FLAG_OBS_SHARED, FLAG_OBS_TILED, FLAG_SLIP_
                    OBS_CONE, OBS_ELLIPSE,
                    OBS_EMPTY, OBS_LANE, OBS_RADIAL)
 
-_DYN = {"dbm": DYN_DBM, "kbm": DYN_KBM, DYN_DBM: DYN_DBM, DYN_KBM: DYN_KBM}
+_DYN = {"dbm": DYN_DBM, "kbm": DYN_KBM, "dum": _lib.DYN_DUM, "sadbm": _lib.DYN_SADBM,
+        DYN_DBM: DYN_DBM, DYN_KBM: DYN_KBM, _lib.DYN_DUM: _lib.DYN_DUM, _lib.DYN_SADBM: _lib.DYN_SADBM}
 
 
 def _ptr(t):
@@ -27,7 +28,9 @@ class BatchedCBF:
 
     Parameters mirror the reference filter objects: alpha (set_alpha), lr/lf or L
     (set_model_params), R (set_qp_cost_weight); dynamics "dbm" = DBM_CBF_2DS
-    (u = [a, delta]) or "kbm" = KBM_VC_CBF2D (u = [v, delta]).
+    (u = [a, delta]), "kbm" = KBM_VC_CBF2D (u = [v, delta]), "dum" = DUM_CBF_2DS
+    (u = [a, omega], no steering transform) or "sadbm" = SADBM_CBF_2DS (u = [a, delta] in and
+    out, the QP works on [a, d(beta)/dt]; solve() then needs `slip` and `dt`).
     lanes_per_qp: 0 lets the library choose; 1/2/4/8/16 cooperating lanes per QP
     with rows in registers; 64 = one wavefront per QP with rows in LDS.
     """
@@ -67,14 +70,22 @@ class BatchedCBF:
 
     # -- the hot path
     def solve(self, state, u_ref, obs, obs_type, u_out=None, status=None, rows_out=None,
-              want_rows=False):
+              want_rows=False, slip=None, dt=None, cone_beta_state=False):
         """state (A,4), u_ref (A,2), obs (M,2,A,4) [or (ceil(A/64),M,2,64,4): tiles of 64 agents,
         see pack_obs_tiled; or (M,2,4): one table shared by all agents], obs_type uint8 (M,)
         [or (M,A)].  Returns (u_out (A,2), status (A,) int32)
         and, with want_rows/rows_out, rows (M,A,4) = Lg_h0, Lg_h1, b, h.
-        Asynchronous on the current stream."""
+        dynamics "sadbm": slip (A,2) = beta, beta_ref_last is read and updated in place, dt is the
+        time step of this call; cone_beta_state makes every cone take the agent's beta
+        (reference cbf/cbf.py:424-427).  Asynchronous on the current stream."""
         if not state.is_cuda:
             raise _lib.SccbfError("BatchedCBF.solve needs tensors on the GPU (no CPU fallback)")
+        sadbm = self.params.dynamics == _lib.DYN_SADBM
+        if sadbm and (slip is None or dt is None):
+            raise ValueError("the steer-rate model needs slip (A,2) and dt")
+        if not sadbm and (slip is not None or cone_beta_state):
+            raise ValueError("slip / cone_beta_state belong to the steer-rate model (dynamics='sadbm')")
+        step = dt
         dt = state.dtype
         if dt not in (torch.float32, torch.float64):
             raise TypeError("state must be float32 or float64")
@@ -108,16 +119,23 @@ class BatchedCBF:
         if want_rows and rows_out is None:
             rows_out = torch.empty((M, A, 4), dtype=dt, device=dev)
         for name, t, shape, dtype in (("u_out", u_out, (A, 2), dt), ("status", status, (A,), torch.int32),
-                                      ("rows_out", rows_out, (M, A, 4), dt)):
+                                      ("rows_out", rows_out, (M, A, 4), dt), ("slip", slip, (A, 2), dt)):
             if t is not None and (tuple(t.shape) != shape or t.dtype != dtype or t.device != dev
                                   or not t.is_contiguous()):
                 raise ValueError("%s: expected contiguous %s %s on %s" % (name, shape, dtype, dev))
+        if cone_beta_state:
+            flags |= _lib.FLAG_CONE_BETA_STATE
         self.params.flags = flags
-        fn = self._lib.sccbf_solve_f32 if dt == torch.float32 else self._lib.sccbf_solve_f64
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
-            rc = fn(C.byref(self.params), A, M, _ptr(state), _ptr(u_ref), _ptr(obs), _ptr(obs_type),
-                    _ptr(u_out), _ptr(status), _ptr(rows_out), C.c_void_p(stream))
+            if sadbm:
+                fn = self._lib.sccbf_solve_sa_f32 if dt == torch.float32 else self._lib.sccbf_solve_sa_f64
+                rc = fn(C.byref(self.params), float(step), A, M, _ptr(state), _ptr(slip), _ptr(u_ref), _ptr(obs),
+                        _ptr(obs_type), _ptr(u_out), _ptr(status), _ptr(rows_out), C.c_void_p(stream))
+            else:
+                fn = self._lib.sccbf_solve_f32 if dt == torch.float32 else self._lib.sccbf_solve_f64
+                rc = fn(C.byref(self.params), A, M, _ptr(state), _ptr(u_ref), _ptr(obs), _ptr(obs_type),
+                        _ptr(u_out), _ptr(status), _ptr(rows_out), C.c_void_p(stream))
         _lib.check(rc)
         if rows_out is not None:
             return u_out, status, rows_out

@@ -68,3 +68,28 @@ def solve(params, s, u_ref, kinds, slots):
                                    C.c_void_p(status.data_ptr()), C.c_void_p(rows.data_ptr()),
                                    C.c_void_p(stream)))
     return u.cpu().numpy()[0], int(status.item()), rows.cpu().numpy()[:, 0, :]
+
+
+def solve_sa(params, dt, s, slip, u_ref, kinds, slots):
+    """One steer-rate QP for one ego (sccbf_solve_sa_f64): returns (u (2,), status, rows (M,4),
+    slip (2,) = beta, beta_ref_last after the call)."""
+    torch = _torch()
+    lib = _lib.load()
+    kinds = np.ascontiguousarray(kinds, dtype=np.uint8)
+    M = kinds.shape[0]
+    dev = torch.device("cuda", torch.cuda.current_device())
+    st = torch.tensor(np.asarray(s, dtype=np.float64).reshape(1, 4), device=dev)
+    sl = torch.tensor(np.asarray(slip, dtype=np.float64).reshape(1, 2), device=dev)
+    ur = torch.tensor(np.asarray(u_ref, dtype=np.float64).reshape(1, 2), device=dev)
+    ob = torch.tensor(_pack(np.asarray(slots, dtype=np.float64)), device=dev)
+    ty = torch.tensor(kinds, device=dev)
+    u = torch.empty((1, 2), dtype=torch.float64, device=dev)
+    status = torch.empty((1,), dtype=torch.int32, device=dev)
+    rows = torch.empty((M, 1, 4), dtype=torch.float64, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    _lib.check(lib.sccbf_solve_sa_f64(C.byref(params), float(dt), 1, M, C.c_void_p(st.data_ptr()),
+                                      C.c_void_p(sl.data_ptr()), C.c_void_p(ur.data_ptr()),
+                                      C.c_void_p(ob.data_ptr()), C.c_void_p(ty.data_ptr()),
+                                      C.c_void_p(u.data_ptr()), C.c_void_p(status.data_ptr()),
+                                      C.c_void_p(rows.data_ptr()), C.c_void_p(stream)))
+    return u.cpu().numpy()[0], int(status.item()), rows.cpu().numpy()[:, 0, :], sl.cpu().numpy()[0]

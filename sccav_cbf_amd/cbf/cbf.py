@@ -12,13 +12,15 @@ reference hands the same problem to cvxopt.solvers.cp (cbf/cbf.py:213).  Results
 length-2 float arrays (the reference returns a 2x1 cvxopt matrix, indexed u[0], u[1]).
 """
 import ctypes as C
+import time
 
 import numpy as np
 
 from .. import _lib
 from . import _device
 from ._vec import Point2
-from .obstacles import ObstacleList2D
+from .obstacles import Obstacle2DTypes, ObstacleList2D
+from .utils import ZERO_TOL
 
 _STATUS = {0: "optimal", 1: "infeasible", 2: "non-finite input"}
 
@@ -100,6 +102,80 @@ class DBM_CBF_2DS(_FilterBase):
 
     def solve_cbf(self, u_ref, return_solver=False):
         info, u = self._solve(u_ref)
+        if return_solver:
+            return info, u
+        return u
+
+
+class DUM_CBF_2DS(DBM_CBF_2DS):
+    """Dynamic unicycle model, u = [a, omega] (reference cbf/cbf.py:222-298): the acceleration
+    drives v, the second input drives the yaw directly, no steering transform.  The reference
+    declares its drift 5x1 with four entries (243-245) and does not run as shipped; this is the
+    model with the 4x1 drift."""
+    _dynamics = _lib.DYN_DUM
+
+    def gc(self, *args, **kwargs):
+        """4x2 (reference cbf/cbf.py:237-239, column lists [0,0,0,1] and [0,0,1,0])."""
+        return np.array([[0.0, 0.0], [0.0, 0.0], [0.0, 1.0], [1.0, 0.0]])
+
+    def fc(self, *args, **kwargs):
+        v, th = self._v, self._theta
+        return np.array([[v * np.cos(th)], [v * np.sin(th)], [0.0], [0.0]])
+
+
+class SADBM_CBF_2DS(DBM_CBF_2DS):
+    """State-augmented, steer-rate controlled dynamic bicycle model (reference
+    cbf/cbf.py:301-437): the slip angle beta is a fifth state, the QP works on
+    [a, d(beta)/dt], solve_cbf takes and returns [a, delta].  dt=None measures the time
+    between calls (cbf.py:361-367, 416-417)."""
+    _dynamics = _lib.DYN_SADBM
+
+    def __init__(self, alpha=1.0, dt=0.001):
+        super().__init__(alpha)
+        self._DT_MODE_AUTO = 0
+        if dt is None:
+            self._DT_MODE_AUTO = 1
+            self._dt = 1e-6
+        else:
+            self._dt = dt
+        self.t_last = time.time()
+        self.beta_ref_last = 0.0
+        self.beta_ref_dot = 0.0
+        self._beta = 0.0
+
+    def gc(self, *args, **kwargs):
+        """5x2 (reference cbf/cbf.py:338-340)."""
+        return np.array([[0.0, 0.0], [0.0, 0.0], [0.0, 0.0], [1.0, 0.0], [0.0, 1.0]])
+
+    def fc(self, *args, **kwargs):
+        """5x1 (reference cbf/cbf.py:342-347)."""
+        v, th, b = self._v, self._theta, self._beta
+        return np.array([[v * np.cos(th + b)], [v * np.sin(th + b)], [v * np.sin(b) / self._lr], [0.0], [0.0]])
+
+    def solve_cbf(self, u_ref, return_solver=False):
+        u_ref = np.asarray(u_ref, dtype=np.float64).reshape(-1)
+        self.t_current = time.time()
+        if self._DT_MODE_AUTO:
+            self._dt = max(self.t_current - self.t_last, ZERO_TOL)
+        if len(self.obstacle_list2d) < 1:
+            # the reference has already advanced its nominal slip angle when it raises (369, 375-378)
+            beta_ref = np.arctan2(self._lr * np.tan(u_ref[1]), self._lf + self._lr)
+            self.beta_ref_dot = (beta_ref - self.beta_ref_last) / self._dt
+            self.beta_ref_last = beta_ref
+            raise ValueError("Cannot solve CBF for an empty obstacle list. Update the obstacle "
+                             "list so that it is non-empty in order to move forward.")
+        kinds, slots = self.obstacle_list2d.slots()
+        last = self.beta_ref_last
+        u, status, rows, slip = _device.solve_sa(self._params(), self._dt, self.s, [self._beta, last], u_ref,
+                                                 kinds, slots)
+        self._beta, self.beta_ref_last = float(slip[0]), float(slip[1])
+        self.beta_ref_dot = (self.beta_ref_last - last) / self._dt
+        # every collision cone follows the filter's slip angle (cbf.py:424-427)
+        for obstacle in self.obstacle_list2d.values():
+            if obstacle.type == Obstacle2DTypes.COLLISION_CONE2D:
+                obstacle.update(beta=self._beta)
+        self.t_last = time.time()
+        info = {"x": u.copy(), "status": _STATUS.get(status, "unknown"), "status_code": status, "rows": rows}
         if return_solver:
             return info, u
         return u

@@ -24,8 +24,10 @@
 //
 // Files: sccbf_common.hip.h (constants, math, cross-lane helpers), sccbf_qp.hip.h (pivot),
 // sccbf_rows.hip.h (barriers and rows), sccbf_filter.hip.h (filter kernels), sccbf_loop.hip.h
-// (nominal controller, vehicle step, rollout); this file: host-side dispatch and the C ABI.
+// (nominal controller, vehicle step, rollout), sccbf_ext.hip.h (unicycle-input and steer-rate
+// models); this file: host-side dispatch and the C ABI.
 #include "sccbf_loop.hip.h"
+#include "sccbf_ext.hip.h"
 
 namespace {
 
@@ -36,7 +38,9 @@ int fill_args(const sccbf_params* sp, int64_t A, int32_t M, KArgs<T>& k)
     if (!sp || A < 0 || M < 0) return SCCBF_ERR_ARG;
     if (A > 0x7fffffffLL) return SCCBF_ERR_ARG;  // the kernels keep strides of up to 2 A in 32 bits
     if (M > SCCBF_MAX_ROWS) return SCCBF_ERR_ROWS;
-    if (sp->dynamics != SCCBF_DYN_DBM && sp->dynamics != SCCBF_DYN_KBM) return SCCBF_ERR_ARG;
+    if (sp->dynamics != SCCBF_DYN_DBM && sp->dynamics != SCCBF_DYN_KBM && sp->dynamics != SCCBF_DYN_DUM &&
+        sp->dynamics != SCCBF_DYN_SADBM)
+        return SCCBF_ERR_ARG;
     if ((sp->flags & SCCBF_FLAG_OBS_SHARED) && (sp->flags & SCCBF_FLAG_OBS_TILED)) return SCCBF_ERR_ARG;
     const double r00 = sp->R[0], r01 = 0.5 * (sp->R[1] + sp->R[2]), r11 = sp->R[3];
     if (!(r00 > 0.0) || !std::isfinite(r00) || !std::isfinite(r01) || !std::isfinite(r11))
@@ -44,7 +48,9 @@ int fill_args(const sccbf_params* sp, int64_t A, int32_t M, KArgs<T>& k)
     const double l00 = std::sqrt(r00), l10 = r01 / l00, t = r11 - l10 * l10;
     if (!(t > 0.0)) return SCCBF_ERR_WEIGHT;
     const double l11 = std::sqrt(t);
-    if (sp->dynamics == SCCBF_DYN_DBM && !(sp->lr > 0.0 && sp->lf + sp->lr > 0.0)) return SCCBF_ERR_ARG;
+    if ((sp->dynamics == SCCBF_DYN_DBM || sp->dynamics == SCCBF_DYN_SADBM) &&
+        !(sp->lr > 0.0 && sp->lf + sp->lr > 0.0))
+        return SCCBF_ERR_ARG;
     if (sp->dynamics == SCCBF_DYN_KBM && !(sp->L > 0.0)) return SCCBF_ERR_ARG;
     k.alpha = (T)sp->alpha; k.lr = (T)sp->lr; k.lf = (T)sp->lf; k.L = (T)sp->L;
     k.inv_lr = (T)(1.0 / sp->lr); k.inv_L = (T)(1.0 / sp->L);
@@ -145,6 +151,36 @@ int dispatch(const sccbf_params* sp, KArgs<T>& k, void* stream)
     }
 }
 
+// unicycle-input and steer-rate models: 4 lanes per QP for large batches, else 16
+template <typename T, int G>
+int launch_ext_rpl(const KArgs<T>& k, const XArgs<T>& x, hipStream_t s)
+{
+    const long long per_block = kBlock / G;
+    const long long blocks = (k.A + per_block - 1) / per_block;
+    if (blocks > 0x7fffffffLL) return SCCBF_ERR_ARG;
+    const int rpl = (k.M + G - 1) / G;
+    const dim3 grid((unsigned)blocks), block(kBlock);
+    if (rpl <= 1) hipLaunchKernelGGL((k_group_ext<T, G, 1>), grid, block, 0, s, k, x);
+    else if (rpl <= 2) hipLaunchKernelGGL((k_group_ext<T, G, 2>), grid, block, 0, s, k, x);
+    else if (rpl <= 4) hipLaunchKernelGGL((k_group_ext<T, G, 4>), grid, block, 0, s, k, x);
+    else if (rpl <= 8) hipLaunchKernelGGL((k_group_ext<T, G, 8>), grid, block, 0, s, k, x);
+    else if (rpl <= 16) hipLaunchKernelGGL((k_group_ext<T, G, 16>), grid, block, 0, s, k, x);
+    else return SCCBF_ERR_ROWS;
+    return hipGetLastError() == hipSuccess ? SCCBF_OK : SCCBF_ERR_LAUNCH;
+}
+
+template <typename T>
+int dispatch_ext(const sccbf_params* sp, const KArgs<T>& k, const XArgs<T>& x, void* stream)
+{
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (k.M > 256) return SCCBF_ERR_ROWS;
+    int lanes = sp->lanes_per_qp;
+    if (lanes == 0) lanes = (k.A >= (1 << 13) && k.M <= 64) ? 4 : 16;
+    if (lanes == 4 && k.M <= 64) return launch_ext_rpl<T, 4>(k, x, s);
+    if (lanes == 16) return launch_ext_rpl<T, 16>(k, x, s);
+    return SCCBF_ERR_VARIANT;
+}
+
 template <typename T>
 int solve_impl(const sccbf_params* sp, int64_t A, int32_t M, const T* state, const T* u_ref,
                const T* obs, const uint8_t* obs_type, T* u_out, int32_t* status, T* rows_out,
@@ -153,11 +189,39 @@ int solve_impl(const sccbf_params* sp, int64_t A, int32_t M, const T* state, con
     KArgs<T> k;
     int rc = fill_args<T>(sp, A, M, k);
     if (rc != SCCBF_OK) return rc;
+    if (sp->dynamics == SCCBF_DYN_SADBM) return SCCBF_ERR_ARG;  // needs the slip state: sccbf_solve_sa_*
     if (A > 0 && (!state || !u_ref || !u_out || !status)) return SCCBF_ERR_ARG;
     if (A > 0 && M > 0 && (!obs || !obs_type)) return SCCBF_ERR_ARG;
     k.state = state; k.u_ref = u_ref; k.obs = obs; k.obs_type = obs_type;
     k.u_out = u_out; k.status = status; k.rows_out = rows_out;
+    if (sp->dynamics == SCCBF_DYN_DUM && A > 0 && M > 0) {
+        if (sp->flags & SCCBF_FLAG_CONE_BETA_STATE) return SCCBF_ERR_ARG;
+        XArgs<T> x;
+        x.slip = nullptr; x.dt = T(0); x.inv_dt = T(0);
+        return dispatch_ext<T>(sp, k, x, stream);
+    }
     return dispatch<T, false>(sp, k, stream);
+}
+
+template <typename T>
+int solve_sa_impl(const sccbf_params* sp, double dt, int64_t A, int32_t M, const T* state, T* slip,
+                  const T* u_ref, const T* obs, const uint8_t* obs_type, T* u_out, int32_t* status,
+                  T* rows_out, void* stream)
+{
+    if (!sp) return SCCBF_ERR_ARG;
+    sccbf_params q = *sp;
+    q.dynamics = SCCBF_DYN_SADBM;
+    KArgs<T> k;
+    int rc = fill_args<T>(&q, A, M, k);
+    if (rc != SCCBF_OK) return rc;
+    if (M < 1 || !(dt > 0.0) || !std::isfinite(dt) || (q.flags & SCCBF_FLAG_SLIP_IO)) return SCCBF_ERR_ARG;
+    if (A == 0) return SCCBF_OK;
+    if (!state || !slip || !u_ref || !u_out || !status || !obs || !obs_type) return SCCBF_ERR_ARG;
+    k.state = state; k.u_ref = u_ref; k.obs = obs; k.obs_type = obs_type;
+    k.u_out = u_out; k.status = status; k.rows_out = rows_out;
+    XArgs<T> x;
+    x.slip = slip; x.dt = (T)dt; x.inv_dt = (T)(1.0 / dt);
+    return dispatch_ext<T>(&q, k, x, stream);
 }
 
 template <typename T>
@@ -342,6 +406,20 @@ int sccbf_solve_f64(const sccbf_params* p, int64_t A, int32_t M, const double* s
                     int32_t* status, double* rows_out, void* stream)
 {
     return solve_impl<double>(p, A, M, state, u_ref, obs, obs_type, u_out, status, rows_out, stream);
+}
+
+int sccbf_solve_sa_f32(const sccbf_params* p, double dt, int64_t A, int32_t M, const float* state,
+                       float* slip, const float* u_ref, const float* obs, const uint8_t* obs_type,
+                       float* u_out, int32_t* status, float* rows_out, void* stream)
+{
+    return solve_sa_impl<float>(p, dt, A, M, state, slip, u_ref, obs, obs_type, u_out, status, rows_out, stream);
+}
+
+int sccbf_solve_sa_f64(const sccbf_params* p, double dt, int64_t A, int32_t M, const double* state,
+                       double* slip, const double* u_ref, const double* obs, const uint8_t* obs_type,
+                       double* u_out, int32_t* status, double* rows_out, void* stream)
+{
+    return solve_sa_impl<double>(p, dt, A, M, state, slip, u_ref, obs, obs_type, u_out, status, rows_out, stream);
 }
 
 int sccbf_qp_f32(const sccbf_params* p, int64_t A, int32_t M, const float* rows, const float* u_nom,

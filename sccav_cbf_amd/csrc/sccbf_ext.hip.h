@@ -1,0 +1,141 @@
+// sccbf_ext.hip.h - the filter for the unicycle-input (DUM) and steer-rate (SADBM) models
+// Part of the sccbf library (one translation unit, see sccbf.hip); device code for gfx950.
+//
+// Same structure as k_group (G lanes per QP, rows in registers and in the per-wavefront LDS
+// table, the same active-set iteration); only the contraction of the partials into a row and
+// the input / output maps differ, so the kernels of the two bicycle models stay as they are.
+#pragma once
+#include "sccbf_filter.hip.h"
+
+namespace {
+
+template <typename T> struct XArgs {
+    T* slip;   // SADBM: [A][2] in/out = beta, beta_ref_last; unused for DUM
+    T dt, inv_dt;
+};
+
+// DUM: reference cbf/cbf.py:237-245, 279-286.   Lg_h = [h_v, h_th],  Lf_h = v (cos(th) h_x + sin(th) h_y)
+// SADBM: reference cbf/cbf.py:338-347, 398-405. Lg_h = [h_v, h_beta],
+//        Lf_h = h_x v cos(th + beta) + h_y v sin(th + beta) + h_th v sin(beta) / lr
+template <typename T>
+__device__ inline void ext_slot_row_(int type, T (&o)[8], const Ego<T>& e, const KArgs<T>& p, bool sadbm,
+                                     bool cone_beta_state, T beta, T cthb, T sthb, T sb,
+                                     T& a0, T& a1, T& b, T& h)
+{
+    Partials<T> d;
+    T hb = T(0);
+    switch (type) {
+    case SCCBF_OBS_ELLIPSE: ellipse_(e.x, e.y, o, d); break;
+    case SCCBF_OBS_CONE:
+        if (cone_beta_state) o[5] = beta;
+        cone_(e.x, e.y, e.th, e.v, e.cth, e.sth, o, p.zero_tol, d);
+        hb = d.hth;  // CollisionCone2D.dbeta, reference cbf/obstacles.py:460-466
+        break;
+    case SCCBF_OBS_LANE: lane_(e.x, e.y, o, p.zero_tol, d); break;
+    case SCCBF_OBS_RADIAL: radial_(e.x, e.y, e.v, o, d); break;
+    default:
+        a0 = T(0); a1 = T(0); b = T(-1); h = T(1);
+        return;
+    }
+    h = d.h;
+    a0 = d.hv;
+    if (sadbm) {
+        a1 = hb;
+        const T lf_h = e.v * (cthb * d.hx + sthb * d.hy) + (e.v * sb * p.inv_lr) * d.hth;
+        b = -(lf_h + p.alpha * d.h + d.ht);
+    } else {
+        a1 = d.hth;
+        const T lf_h = e.v * (e.cth * d.hx + e.sth * d.hy);
+        b = -(lf_h + p.alpha * d.h + d.ht);
+    }
+}
+
+template <typename T, int G, int RPL>
+__global__ __launch_bounds__(kBlock) void k_group_ext(const KArgs<T> p, const XArgs<T> x)
+{
+    using v4 = typename VT<T>::v4;
+    using v2 = typename VT<T>::v2;
+    const int g = (int)(threadIdx.x % G);
+    const long long qp = (long long)blockIdx.x * (kBlock / G) + threadIdx.x / G;
+    if (qp >= p.A) return;  // groups are lane-aligned: a whole group leaves together
+    const bool sadbm = p.dynamics == SCCBF_DYN_SADBM;
+    v2 sl = v2{T(0), T(0)};
+    if (sadbm) sl = reinterpret_cast<const v2*>(x.slip)[qp];
+    LaneLoads<T, RPL> L;
+    group_load_<T, RPL, false, false>(p, qp, g, G, L);
+
+    Ego<T> e;
+    e.x = L.sv.x; e.y = L.sv.y; e.th = L.sv.z; e.v = L.sv.w;
+    const T ur0 = L.urv.x, ur1 = L.urv.y;
+    int bad = !(finite_(ur0) && finite_(ur1) && finite_(e.x) && finite_(e.y) && finite_(e.th) && finite_(e.v) &&
+                finite_(sl.x) && finite_(sl.y));
+    sincos_(e.th, &e.sth, &e.cth);
+    T beta_ref = T(0), cthb = e.cth, sthb = e.sth, sb = T(0);
+    e.un0 = ur0;
+    e.un1 = ur1;
+    if (sadbm) {
+        beta_ref = atan_(tan_(ur1) * p.k_in);       // reference cbf/cbf.py:359
+        e.un1 = (beta_ref - sl.y) * x.inv_dt;       // cbf.py:367-372
+        T cb;
+        sincos_(e.th + sl.x, &sthb, &cthb);
+        sincos_(sl.x, &sb, &cb);
+    }
+    const bool cone_beta_state = sadbm && (p.flags & SCCBF_FLAG_CONE_BETA_STATE) != 0;
+
+    T at0[RPL], at1[RPL], bt[RPL];
+    T chk = T(0);
+#pragma unroll
+    for (int r = 0; r < RPL; ++r) {
+        const int m = g + r * G;
+        T o[8] = {L.oa[r].x, L.oa[r].y, L.oa[r].z, L.oa[r].w, L.ob[r].x, L.ob[r].y, L.ob[r].z, L.ob[r].w};
+        const int ty = m < p.M ? L.ty[r] : SCCBF_OBS_EMPTY;
+        T a0, a1, b, h;
+        ext_slot_row_(ty, o, e, p, sadbm, cone_beta_state, sl.x, cthb, sthb, sb, a0, a1, b, h);
+        if (p.rows_out && m < p.M) reinterpret_cast<v4*>(p.rows_out)[(long long)m * p.A + qp] = v4{a0, a1, b, h};
+        chk += a0 * T(0) + a1 * T(0) + b * T(0);
+        to_wspace_(a0, a1, b, e, p, at0[r], at1[r], bt[r]);
+    }
+    bad |= !(chk == T(0));
+    bad = (int)group_or<G>((unsigned)bad);
+
+    constexpr int kMpad = G * RPL + 1;
+    constexpr int kPlane = (kBlock / G) * kMpad;
+    constexpr bool kLdsPick = (size_t)3 * kPlane * sizeof(T) <= 53 * 1024;
+    __shared__ T s_rows[kLdsPick ? 3 * kPlane : 1];
+    const int qslot = (int)(threadIdx.x / G) * kMpad;
+    if (kLdsPick) {
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) {
+            s_rows[qslot + r * G + g] = at0[r];
+            s_rows[kPlane + qslot + r * G + g] = at1[r];
+            s_rows[2 * kPlane + qslot + r * G + g] = bt[r];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    const Pivot<T> s = active_set_<T, G, RPL, kLdsPick>(p.M, g, at0, at1, bt, s_rows, kPlane, qslot, bad);
+    if (g != 0) return;
+
+    // u = u_nom + Lc^-T w, or the nominal input when the QP has no answer
+    T u0 = e.un0, u1 = e.un1;
+    if (s.st == SCCBF_STATUS_OPTIMAL) {
+        const T y1 = s.w1 * p.inv_l11;
+        const T y0 = (s.w0 - p.l10 * y1) * p.inv_l00;
+        u0 += y0;
+        u1 += y1;
+    }
+    v2 out = v2{u0, u1};
+    if (sadbm) {
+        if (s.st == SCCBF_STATUS_NONFINITE) {
+            out = v2{ur0, ur1};  // nothing to integrate: inputs pass through, the slip state stays
+        } else {
+            const T beta = sl.x + u1 * x.dt;            // reference cbf/cbf.py:421
+            out.y = atan_(tan_(beta) * p.k_out);        // cbf.py:430
+            reinterpret_cast<v2*>(x.slip)[qp] = v2{beta, beta_ref};
+        }
+    }
+    reinterpret_cast<v2*>(p.u_out)[qp] = out;
+    p.status[qp] = s.st;
+}
+
+}  // namespace

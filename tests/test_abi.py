@@ -118,6 +118,31 @@ def test_rollout_argument_validation(lib):
     assert lib.sccbf_rollout_f64(None, C.byref(q), C.byref(r), 8, 4, 100, *nul) == -1
 
 
+def test_model_variants_argument_validation(lib):
+    p = _lib.Params()
+    lib.sccbf_default_params(C.byref(p))
+    nul = (C.c_void_p(0),) * 8
+    p.dynamics = _lib.DYN_SADBM
+    assert lib.sccbf_solve_f64(C.byref(p), 8, 4, *nul) == -1           # the steer-rate model needs its slip state
+    p.dynamics = _lib.DYN_DUM
+    assert lib.sccbf_solve_f64(C.byref(p), 0, 4, *nul) == 0
+    assert lib.sccbf_solve_f64(C.byref(p), 8, 4, *nul) == -1           # null data
+    p.dynamics = 7
+    assert lib.sccbf_solve_f64(C.byref(p), 0, 4, *nul) == -1
+    p.dynamics = 0                                                       # ignored by sccbf_solve_sa_*
+    nul9 = (C.c_void_p(0),) * 9
+    sa = lambda dt, A, M: lib.sccbf_solve_sa_f32(C.byref(p), dt, A, M, *nul9)
+    assert sa(0.1, 0, 4) == 0
+    assert sa(0.1, 8, 4) == -1                                           # null data
+    assert sa(0.0, 0, 4) == -1 and sa(float("nan"), 0, 4) == -1 and sa(-1.0, 0, 4) == -1
+    assert sa(0.1, 0, 0) == -1                                           # an empty list raises in the reference
+    assert sa(0.1, 0, 1025) == -2
+    p.flags = _lib.FLAG_SLIP_IO
+    assert sa(0.1, 0, 4) == -1
+    p.flags = 0
+    assert lib.sccbf_solve_sa_f64(None, 0.1, 0, 4, *nul9) == -1
+
+
 def test_no_cpu_fallback_in_front_end():
     """Without a GPU the batched front-end must refuse, not compute somewhere else."""
     import numpy as np
