@@ -320,6 +320,43 @@ int sccbf_rollout_f64(const sccbf_params* p, const sccbf_nominal_params* np,
                       double* h_min, int32_t* n_active, int32_t* n_infeasible, double* trace,
                       void* stream);
 
+/*
+ * Bounding boxes -> obstacle slots, for A agents with M boxes each: what
+ * ObstacleList2D.update_by_bounding_box (reference cbf/obstacles.py:833-858) builds per box.
+ *   bbox  T[M][2][A][4]  location x, y, extent x, y | yaw, speed, -, -   (BoundingBox, 59-64)
+ *   kind  u8[M] (u8[M][A] with SCCBF_FLAG_TYPE_PER_AGENT), afterwards the obs_type of the filter:
+ *         SCCBF_OBS_ELLIPSE  Ellipse2D.from_bounding_box (320-331): a = extent x + buffer,
+ *                            b = extent y + buffer, theta_o = yaw, at rest
+ *         SCCBF_OBS_CONE     CollisionCone2D.from_bounding_box (534-543): a = hypot(extent x,
+ *                            extent y) + buffer, theta_o = 0, v_o = speed
+ *         anything else      an all-zero slot (pair it with SCCBF_OBS_EMPTY)
+ *   obs   out, T[M][2][A][4], or tiles with SCCBF_FLAG_OBS_TILED in flags
+ */
+int sccbf_ingest_bbox_f32(int64_t A, int32_t M, const float* bbox, const uint8_t* kind,
+                          double buffer, uint32_t flags, float* obs, void* stream);
+int sccbf_ingest_bbox_f64(int64_t A, int32_t M, const double* bbox, const uint8_t* kind,
+                          double buffer, uint32_t flags, double* obs, void* stream);
+
+/*
+ * Lane points -> lane slot m of every agent: PolyLane.fit_polynomial_curve, reference
+ * cbf/obstacles.py:715-773, the polynomial of degree 0..3 that minimises
+ * sum(((p(x_k) - y_k) / sigma_k)^2).
+ *   px, py  T[K][A]   K >= 1 points per agent
+ *   sigma   T[K][A]   standard deviations, or NULL for 10 everywhere (737-738); the reference's
+ *                     fixed points are points with a small sigma (alpha = 0.01, 753-756); a
+ *                     point with sigma <= 0 or a non-finite value is skipped (ragged counts)
+ *   obs     in/out: only slot m (0 <= m < M) is written, c0..c3 | buffer, 0, 0, 0; layout as in
+ *           sccbf_solve_* (planes, or tiles with SCCBF_FLAG_OBS_TILED in flags)
+ * Fewer usable points than coefficients, or points that do not determine them: NaN coefficients
+ * (the filter then reports SCCBF_STATUS_NONFINITE for that agent).
+ */
+int sccbf_lane_fit_f32(int64_t A, int32_t K, int32_t degree, const float* px, const float* py,
+                       const float* sigma, double buffer, int32_t m, int32_t M, uint32_t flags,
+                       float* obs, void* stream);
+int sccbf_lane_fit_f64(int64_t A, int32_t K, int32_t degree, const double* px, const double* py,
+                       const double* sigma, double buffer, int32_t m, int32_t M, uint32_t flags,
+                       double* obs, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

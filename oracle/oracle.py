@@ -257,3 +257,45 @@ def seeker_step(obs, obs_type, ego_xy, dt, k=0.2, v_min=3.0):
             ang = obs[m, 0, :, 2] + obs[m, 1, :, 1]
             obs[m, 0, :, 0] += obs[m, 0, :, 3] * np.cos(ang) * dt
             obs[m, 0, :, 1] += obs[m, 0, :, 3] * np.sin(ang) * dt
+
+
+def ingest_bbox(bbox, kind, buffer=0.5):
+    """Slots (M,2,A,4) from bounding boxes (M,2,A,4) = location x, y, extent x, y | yaw, speed:
+    Ellipse2D.from_bounding_box (cbf/obstacles.py:320-331: a = extent.x, b = extent.y, centre,
+    theta = yaw, buffer added to both axes by the constructor, 146-162) and
+    CollisionCone2D.from_bounding_box (534-543: a = hypot(extent.x, extent.y) + buffer (357),
+    s_obs = [x, y, 0, velocity]).  kind (M,) or (M,A)."""
+    bbox = _f64(bbox)
+    M, A = bbox.shape[0], bbox.shape[2]
+    kind = np.broadcast_to(np.asarray(kind, dtype=np.uint8).reshape(M, -1), (M, A))
+    obs = np.zeros((M, 2, A, 4))
+    x, y, ex, ey, yaw, sp = (bbox[:, 0, :, 0], bbox[:, 0, :, 1], bbox[:, 0, :, 2], bbox[:, 0, :, 3],
+                             bbox[:, 1, :, 0], bbox[:, 1, :, 1])
+    e, c = kind == OBS_ELLIPSE, kind == OBS_CONE
+    obs[:, 0, :, 0] = np.where(e | c, x, 0.0)
+    obs[:, 0, :, 1] = np.where(e | c, y, 0.0)
+    obs[:, 0, :, 2] = np.where(e, ex + buffer, 0.0)
+    obs[:, 0, :, 3] = np.where(e, ey + buffer, np.where(c, sp, 0.0))
+    obs[:, 1, :, 0] = np.where(e, yaw, np.where(c, np.hypot(ex, ey) + buffer, 0.0))
+    return obs
+
+
+def lane_fit(px, py, sigma=None, degree=3):
+    """PolyLane.fit_polynomial_curve, cbf/obstacles.py:715-773, per agent: the coefficients
+    (A, 4), lowest power first, that minimise sum(((p(x) - y) / sigma)^2): the objective of the
+    scipy.optimize.curve_fit call at 768-772 for the polynomial model of 765-766.  px, py, sigma
+    are (K, A); sigma None = 10 everywhere (737-738); points with sigma <= 0 are left out."""
+    px, py = _f64(px), _f64(py)
+    K, A = px.shape
+    sg = np.full((K, A), 10.0) if sigma is None else _f64(sigma)
+    out = np.zeros((A, 4))
+    for a in range(A):
+        use = sg[:, a] > 0
+        x, y, s = px[use, a], py[use, a], sg[use, a]
+        xc, hs = 0.5 * (x.min() + x.max()), 0.5 * (x.max() - x.min()) or 1.0
+        V = np.vander((x - xc) / hs, degree + 1, increasing=True) / s[:, None]
+        d, *_ = np.linalg.lstsq(V, y / s, rcond=None)
+        p = np.polynomial.Polynomial(d, domain=[xc - hs, xc + hs], window=[-1, 1]).convert(
+            domain=[-1, 1], window=[-1, 1])
+        out[a, :p.coef.size] = p.coef
+    return out

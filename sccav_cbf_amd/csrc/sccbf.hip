@@ -25,9 +25,11 @@
 // Files: sccbf_common.hip.h (constants, math, cross-lane helpers), sccbf_qp.hip.h (pivot),
 // sccbf_rows.hip.h (barriers and rows), sccbf_filter.hip.h (filter kernels), sccbf_loop.hip.h
 // (nominal controller, vehicle step, rollout), sccbf_ext.hip.h (unicycle-input and steer-rate
-// models); this file: host-side dispatch and the C ABI.
+// models), sccbf_ingest.hip.h (bounding boxes and lane points -> slots); this file: host-side
+// dispatch and the C ABI.
 #include "sccbf_loop.hip.h"
 #include "sccbf_ext.hip.h"
+#include "sccbf_ingest.hip.h"
 
 namespace {
 
@@ -359,9 +361,70 @@ int rollout_impl(const sccbf_params* sp, const sccbf_nominal_params* np, const s
     return launch_rollout<T, 16>(r, s);
 }
 
+template <typename T>
+int ingest_impl(int64_t A, int32_t M, const T* bbox, const uint8_t* kind, double buffer, uint32_t flags,
+                T* obs, void* stream)
+{
+    if (A < 0 || M < 0 || A > 0x7fffffffLL || M > SCCBF_MAX_ROWS || !std::isfinite(buffer)) return SCCBF_ERR_ARG;
+    if (flags & ~(SCCBF_FLAG_TYPE_PER_AGENT | SCCBF_FLAG_OBS_TILED)) return SCCBF_ERR_ARG;
+    if (A == 0 || M == 0) return SCCBF_OK;
+    if (!bbox || !kind || !obs) return SCCBF_ERR_ARG;
+    IArgs<T> k;
+    k.A = A; k.M = M; k.flags = flags; k.bbox = bbox; k.kind = kind; k.buffer = (T)buffer; k.obs = obs;
+    const long long blocks = (A * M + kBlock - 1) / kBlock;
+    if (blocks > 0x7fffffffLL) return SCCBF_ERR_ARG;
+    hipLaunchKernelGGL((k_ingest<T>), dim3((unsigned)blocks), dim3(kBlock), 0,
+                       reinterpret_cast<hipStream_t>(stream), k);
+    return hipGetLastError() == hipSuccess ? SCCBF_OK : SCCBF_ERR_LAUNCH;
+}
+
+template <typename T>
+int lane_fit_impl(int64_t A, int32_t K, int32_t degree, const T* px, const T* py, const T* sigma, double buffer,
+                  int32_t m, int32_t M, uint32_t flags, T* obs, void* stream)
+{
+    if (A < 0 || A > 0x7fffffffLL || K < 1 || degree < 0 || degree > 3 || !std::isfinite(buffer)) return SCCBF_ERR_ARG;
+    if (M < 1 || M > SCCBF_MAX_ROWS || m < 0 || m >= M) return SCCBF_ERR_ARG;
+    if (flags & ~SCCBF_FLAG_OBS_TILED) return SCCBF_ERR_ARG;
+    if (A == 0) return SCCBF_OK;
+    if (!px || !py || !obs) return SCCBF_ERR_ARG;
+    FArgs<T> k;
+    k.A = A; k.K = K; k.degree = degree; k.m = m; k.M = M; k.flags = flags;
+    k.px = px; k.py = py; k.sigma = sigma; k.buffer = (T)buffer; k.obs = obs;
+    const long long blocks = (A + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL((k_lane_fit<T>), dim3((unsigned)blocks), dim3(kBlock), 0,
+                       reinterpret_cast<hipStream_t>(stream), k);
+    return hipGetLastError() == hipSuccess ? SCCBF_OK : SCCBF_ERR_LAUNCH;
+}
+
 }  // namespace
 
 extern "C" {
+
+int sccbf_ingest_bbox_f32(int64_t A, int32_t M, const float* bbox, const uint8_t* kind, double buffer,
+                          uint32_t flags, float* obs, void* stream)
+{
+    return ingest_impl<float>(A, M, bbox, kind, buffer, flags, obs, stream);
+}
+
+int sccbf_ingest_bbox_f64(int64_t A, int32_t M, const double* bbox, const uint8_t* kind, double buffer,
+                          uint32_t flags, double* obs, void* stream)
+{
+    return ingest_impl<double>(A, M, bbox, kind, buffer, flags, obs, stream);
+}
+
+int sccbf_lane_fit_f32(int64_t A, int32_t K, int32_t degree, const float* px, const float* py,
+                       const float* sigma, double buffer, int32_t m, int32_t M, uint32_t flags, float* obs,
+                       void* stream)
+{
+    return lane_fit_impl<float>(A, K, degree, px, py, sigma, buffer, m, M, flags, obs, stream);
+}
+
+int sccbf_lane_fit_f64(int64_t A, int32_t K, int32_t degree, const double* px, const double* py,
+                       const double* sigma, double buffer, int32_t m, int32_t M, uint32_t flags, double* obs,
+                       void* stream)
+{
+    return lane_fit_impl<double>(A, K, degree, px, py, sigma, buffer, m, M, flags, obs, stream);
+}
 
 int sccbf_version(void) { return SCCBF_VERSION; }
 

@@ -1,0 +1,158 @@
+// sccbf_ingest.hip.h - in front of the filter: bounding boxes -> obstacle slots, lane points -> lane slots
+// Part of the sccbf library (one translation unit, see sccbf.hip); device code for gfx950.
+#pragma once
+#include "sccbf_rows.hip.h"
+
+namespace {
+
+template <typename T> struct IArgs {
+    long long A;
+    int M;
+    unsigned flags;      // SCCBF_FLAG_TYPE_PER_AGENT (kind), SCCBF_FLAG_OBS_TILED (layout of obs)
+    const T* bbox;       // [M][2][A][4] = loc_x, loc_y, ext_x, ext_y | yaw, speed, -, -
+    const uint8_t* kind; // [M] or [M][A]
+    T buffer;
+    T* obs;
+};
+
+// index of the first 4-vector of slot m of agent a in obs, and the distance to the second
+template <typename T> __device__ inline ObsAddr slot_addr_(long long A, int M, unsigned flags, long long a)
+{
+    KArgs<T> k;
+    k.A = A; k.M = M; k.flags = flags & SCCBF_FLAG_OBS_TILED;
+    return obs_addr_(k, a);
+}
+
+// One thread per (slot, agent).  Ellipse2D.from_bounding_box, reference cbf/obstacles.py:320-331
+// (a = extent.x, b = extent.y, centre, theta = yaw, buffer on both axes, no velocity);
+// CollisionCone2D.from_bounding_box, 534-543 (a = hypot(extent.x, extent.y) + buffer,
+// s_obs = [x, y, 0, velocity]).  Any other kind leaves an all-zero slot.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_ingest(const IArgs<T> p)
+{
+    using v4 = typename VT<T>::v4;
+    const long long gid = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (gid >= p.A * p.M) return;
+    const int m = (int)(gid / p.A);
+    const long long a = gid % p.A;
+    const v4* in = reinterpret_cast<const v4*>(p.bbox);
+    const v4 b0 = in[(long long)m * 2 * p.A + a];
+    const v4 b1 = in[(long long)m * 2 * p.A + p.A + a];
+    const int kind = (p.flags & SCCBF_FLAG_TYPE_PER_AGENT) ? p.kind[(long long)m * p.A + a] : p.kind[m];
+    v4 oa = v4{T(0), T(0), T(0), T(0)}, ob = oa;
+    if (kind == SCCBF_OBS_ELLIPSE) {
+        oa = v4{b0.x, b0.y, b0.z + p.buffer, b0.w + p.buffer};
+        ob = v4{b1.x, T(0), T(0), T(0)};
+    } else if (kind == SCCBF_OBS_CONE) {
+        oa = v4{b0.x, b0.y, T(0), b1.y};
+        ob = v4{sqrt_(b0.z * b0.z + b0.w * b0.w) + p.buffer, T(0), T(0), T(0)};
+    }
+    const ObsAddr ad = slot_addr_<T>(p.A, p.M, p.flags, a);
+    v4* out = reinterpret_cast<v4*>(p.obs);
+    out[ad.at(m)] = oa;
+    out[ad.at(m) + ad.half] = ob;
+}
+
+template <typename T> struct FArgs {
+    long long A;
+    int K, degree, m, M;
+    unsigned flags;
+    const T* px;     // [K][A]
+    const T* py;     // [K][A]
+    const T* sigma;  // [K][A] or null (every point 10, reference cbf/obstacles.py:737-738)
+    T buffer;
+    T* obs;
+};
+
+// PolyLane.fit_polynomial_curve, reference cbf/obstacles.py:715-773: the polynomial of the given
+// degree that minimises sum(((p(x_i) - y_i) / sigma_i)^2) (what scipy.optimize.curve_fit minimises
+// there for a model that is linear in its coefficients).  One thread per agent, fp64 throughout:
+// normal equations in t = (x - centre) / half-range (moments of |t| <= 1), Cholesky, then the
+// coefficients of the powers of x.  Points with sigma <= 0 or a non-finite value are skipped; if
+// the points do not determine the polynomial the coefficients are NaN (the filter then reports
+// the agent as non-finite).
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_lane_fit(const FArgs<T> p)
+{
+    using v4 = typename VT<T>::v4;
+    const long long a = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (a >= p.A) return;
+    const int n = p.degree + 1;
+    double xmin = INFINITY, xmax = -INFINITY;
+    int cnt = 0;
+    for (int k = 0; k < p.K; ++k) {
+        const double x = (double)p.px[(long long)k * p.A + a], y = (double)p.py[(long long)k * p.A + a];
+        const double sg = p.sigma ? (double)p.sigma[(long long)k * p.A + a] : 10.0;
+        if (!(sg > 0.0) || !isfinite(sg) || !isfinite(x) || !isfinite(y)) continue;
+        xmin = fmin(xmin, x);
+        xmax = fmax(xmax, x);
+        ++cnt;
+    }
+    const double xc = 0.5 * (xmin + xmax);
+    double hs = 0.5 * (xmax - xmin);
+    if (!(hs > 0.0)) hs = 1.0;
+    const double ihs = 1.0 / hs;
+    double S[7] = {0, 0, 0, 0, 0, 0, 0}, B[4] = {0, 0, 0, 0};
+    for (int k = 0; k < p.K; ++k) {
+        const double x = (double)p.px[(long long)k * p.A + a], y = (double)p.py[(long long)k * p.A + a];
+        const double sg = p.sigma ? (double)p.sigma[(long long)k * p.A + a] : 10.0;
+        if (!(sg > 0.0) || !isfinite(sg) || !isfinite(x) || !isfinite(y)) continue;
+        const double w = 1.0 / (sg * sg), t = (x - xc) * ihs;
+        double tj = w;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            S[j] += tj;
+            if (j < 4) B[j] += tj * y;
+            tj *= t;
+        }
+    }
+    // Cholesky of G[i][j] = S[i + j], i, j < n
+    double Lc[4][4];
+    double d[4] = {0, 0, 0, 0};
+    bool ok = cnt >= n;
+    for (int i = 0; i < 4; ++i) {
+        if (i >= n) break;
+        for (int j = 0; j <= i; ++j) {
+            double s = S[i + j];
+            for (int q = 0; q < j; ++q) s -= Lc[i][q] * Lc[j][q];
+            if (i == j) {
+                if (!(s > 1e-13 * S[2 * i])) { ok = false; s = 1.0; }
+                Lc[i][i] = sqrt(s);
+            } else {
+                Lc[i][j] = s / Lc[j][j];
+            }
+        }
+    }
+    for (int i = 0; i < n; ++i) {  // L z = B
+        double s = B[i];
+        for (int q = 0; q < i; ++q) s -= Lc[i][q] * d[q];
+        d[i] = s / Lc[i][i];
+    }
+    for (int i = n - 1; i >= 0; --i) {  // L^T d = z
+        double s = d[i];
+        for (int q = i + 1; q < n; ++q) s -= Lc[q][i] * d[q];
+        d[i] = s / Lc[i][i];
+    }
+    // p(x) = sum_j d_j ((x - xc) / hs)^j  ->  coefficients of x^k
+    double e[4], c[4] = {0, 0, 0, 0};
+    double sc = 1.0;
+    for (int j = 0; j < 4; ++j) {
+        e[j] = j < n ? d[j] * sc : 0.0;
+        sc *= ihs;
+    }
+    const double binom[4][4] = {{1, 0, 0, 0}, {1, 1, 0, 0}, {1, 2, 1, 0}, {1, 3, 3, 1}};
+    for (int j = 0; j < 4; ++j) {
+        double pw = 1.0;  // (-xc)^(j - k), k from j down to 0
+        for (int k = j; k >= 0; --k) {
+            c[k] += e[j] * binom[j][k] * pw;
+            pw *= -xc;
+        }
+    }
+    if (!ok) c[0] = c[1] = c[2] = c[3] = NAN;
+    const ObsAddr ad = slot_addr_<T>(p.A, p.M, p.flags, a);
+    v4* out = reinterpret_cast<v4*>(p.obs);
+    out[ad.at(p.m)] = v4{(T)c[0], (T)c[1], (T)c[2], (T)c[3]};
+    out[ad.at(p.m) + ad.half] = v4{p.buffer, T(0), T(0), T(0)};
+}
+
+}  // namespace

@@ -1,0 +1,82 @@
+"""In front of the filter, on the GPU: bounding boxes -> obstacle slots, lane points -> lane slots.
+
+ingest_bbox   what ObstacleList2D.update_by_bounding_box builds per box (reference
+              cbf/obstacles.py:833-858 with Ellipse2D.from_bounding_box 320-331 and
+              CollisionCone2D.from_bounding_box 534-543), for a whole batch.
+lane_fit      PolyLane.fit_polynomial_curve (cbf/obstacles.py:715-773) for every agent's lane points.
+
+All arithmetic is in libsccbf.so; tensors hold device memory and the current stream.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from .batched import _ptr
+
+
+def _need_gpu(t, what):
+    if not t.is_cuda:
+        raise _lib.SccbfError("%s needs tensors on the GPU (no CPU fallback)" % what)
+    if t.dtype not in (torch.float32, torch.float64):
+        raise TypeError("%s works on float32 or float64 tensors" % what)
+
+
+def _check(name, t, shape, dtype, dev):
+    if tuple(t.shape) != tuple(shape) or t.dtype != dtype or t.device != dev or not t.is_contiguous():
+        raise ValueError("%s: expected contiguous %s %s on %s, got %s %s on %s" % (
+            name, tuple(shape), dtype, dev, tuple(t.shape), t.dtype, t.device))
+
+
+def _obs_shape(A, M, tiled):
+    return ((A + 63) // 64, M, 2, 64, 4) if tiled else (M, 2, A, 4)
+
+
+def ingest_bbox(bbox, kind, buffer=0.5, tiled=False, out=None):
+    """bbox (M,2,A,4) = location x, y, extent x, y | yaw, speed, -, -; kind uint8 (M,) or (M,A) with
+    OBS_ELLIPSE / OBS_CONE (anything else: an all-zero slot).  Returns obs in the planes layout
+    (M,2,A,4) or, with tiled=True, in 64-agent tiles; `kind` is the obs_type of the solve."""
+    _need_gpu(bbox, "ingest_bbox")
+    M, A = bbox.shape[0], bbox.shape[2]
+    dev, ty = bbox.device, bbox.dtype
+    _check("bbox", bbox, (M, 2, A, 4), ty, dev)
+    flags = _lib.FLAG_OBS_TILED if tiled else 0
+    if kind.dim() == 2:
+        flags |= _lib.FLAG_TYPE_PER_AGENT
+        _check("kind", kind, (M, A), torch.uint8, dev)
+    else:
+        _check("kind", kind, (M,), torch.uint8, dev)
+    if out is None:
+        out = torch.zeros(_obs_shape(A, M, tiled), dtype=ty, device=dev)
+    _check("out", out, _obs_shape(A, M, tiled), ty, dev)
+    lib = _lib.load()
+    fn = lib.sccbf_ingest_bbox_f32 if ty == torch.float32 else lib.sccbf_ingest_bbox_f64
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        rc = fn(A, M, _ptr(bbox), _ptr(kind), float(buffer), flags, _ptr(out), C.c_void_p(stream))
+    _lib.check(rc)
+    return out
+
+
+def lane_fit(px, py, obs, slot, sigma=None, degree=3, buffer=1.5):
+    """px, py (K,A): lane points of every agent; sigma (K,A) or None (10 everywhere; a fixed point
+    is a point with a small sigma, a point with sigma <= 0 is skipped).  Writes lane slot `slot`
+    of obs (planes (M,2,A,4) or tiles (ceil(A/64),M,2,64,4)) in place and returns obs."""
+    _need_gpu(px, "lane_fit")
+    K, A = px.shape
+    dev, ty = px.device, px.dtype
+    _check("px", px, (K, A), ty, dev)
+    _check("py", py, (K, A), ty, dev)
+    if sigma is not None:
+        _check("sigma", sigma, (K, A), ty, dev)
+    tiled = obs.dim() == 5
+    M = obs.shape[1] if tiled else obs.shape[0]
+    _check("obs", obs, _obs_shape(A, M, tiled), ty, dev)
+    lib = _lib.load()
+    fn = lib.sccbf_lane_fit_f32 if ty == torch.float32 else lib.sccbf_lane_fit_f64
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        rc = fn(A, K, int(degree), _ptr(px), _ptr(py), _ptr(sigma), float(buffer), int(slot), M,
+                _lib.FLAG_OBS_TILED if tiled else 0, _ptr(obs), C.c_void_p(stream))
+    _lib.check(rc)
+    return obs

@@ -143,6 +143,21 @@ def test_model_variants_argument_validation(lib):
     assert lib.sccbf_solve_sa_f64(None, 0.1, 0, 4, *nul9) == -1
 
 
+def test_ingest_and_lane_fit_argument_validation(lib):
+    nul = C.c_void_p(0)
+    ing = lambda A, M, buf=0.5, flags=0: lib.sccbf_ingest_bbox_f32(A, M, nul, nul, buf, flags, nul, nul)
+    assert ing(0, 4) == 0 and ing(8, 0) == 0
+    assert ing(8, 4) == -1                                   # null data
+    assert ing(-1, 4) == -1 and ing(8, 1025) == -1 and ing(8, 4, float("nan")) == -1
+    assert ing(0, 4, 0.5, _lib.FLAG_OBS_SHARED) == -1        # only the per-agent-kind and tiled flags apply
+    fit = lambda A, K, deg, m, M, flags=0: lib.sccbf_lane_fit_f64(A, K, deg, nul, nul, nul, 1.5, m, M, flags, nul, nul)
+    assert fit(0, 8, 3, 0, 2) == 0
+    assert fit(8, 8, 3, 0, 2) == -1                          # null data
+    assert fit(0, 0, 3, 0, 2) == -1 and fit(0, 8, 4, 0, 2) == -1 and fit(0, 8, -1, 0, 2) == -1
+    assert fit(0, 8, 3, 2, 2) == -1 and fit(0, 8, 3, -1, 2) == -1 and fit(0, 8, 3, 0, 0) == -1
+    assert fit(0, 8, 3, 0, 2, _lib.FLAG_TYPE_PER_AGENT) == -1
+
+
 def test_no_cpu_fallback_in_front_end():
     """Without a GPU the batched front-end must refuse, not compute somewhere else."""
     import numpy as np
