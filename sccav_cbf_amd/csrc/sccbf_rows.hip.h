@@ -210,9 +210,11 @@ __device__ inline void to_wspace_(T a0, T a1, T b, const Ego<T>& e, const KArgs<
         at1 = t1 * inv;
         bt = rhs * inv;
     } else {
+        // 0 . u >= rhs holds for every u or for none: a positive rhs must win every comparison of
+        // violations, whatever tolerance the size of w has earned the other rows by then
         at0 = T(0);
         at1 = T(0);
-        bt = rhs;
+        bt = rhs > Lim<T>::tiny_n2 ? T(INFINITY) : rhs;
     }
 }
 

@@ -222,6 +222,25 @@ def test_qp_stage_adversarial_rows(oracle, lanes):
     assert np.abs(ug - uo).max() <= 1e-6 * (1 + np.abs(uo).max())
 
 
+@pytest.mark.parametrize("dtype,b2", [(torch.float64, 1e-10), (torch.float32, 5e-4)], ids=["f64", "f32"])
+@pytest.mark.parametrize("lanes", ALL_LANES)
+def test_impossible_row_behind_a_far_optimum(oracle, lanes, dtype, b2):
+    """0 . u >= b2 > 0 admits no u, however small b2 is against the size of the optimum of the other
+    rows (here 479 away, where a unit-normal row would be granted that much rounding slack)."""
+    rows = np.zeros((2, 3, 4))
+    rows[0, :, :3] = (-0.0452329, 0.0, 21.6777)
+    rows[1, 0, :3] = (0.0, 0.0, b2)          # impossible
+    rows[1, 1, :3] = (0.0, 0.0, -b2)         # always true
+    rows[1, 2, :3] = (0.0, 0.0, 0.0)         # always true
+    un = np.tile([-1.7, 0.4], (3, 1))
+    _, so = oracle.qp_batch(oracle.make_params(R=(0.5, 0, 0, 0.5)), rows, un)
+    f = _filter(lanes=lanes)
+    ug, sg = f.solve_qp(torch.from_numpy(rows).to(_dev()).to(dtype), torch.from_numpy(un).to(_dev()).to(dtype))
+    torch.cuda.synchronize()
+    assert so.tolist() == [1, 0, 0] and sg.cpu().tolist() == [1, 0, 0]
+    assert abs(float(ug[1, 0]) + 21.6777 / 0.0452329) < 1e-2
+
+
 @pytest.mark.parametrize("lanes", ALL_LANES)
 @pytest.mark.parametrize("M", [0, 1, 2, 3, 5, 8, 9, 16, 17, 31, 32, 33, 64])
 def test_row_counts_and_ragged_batches(oracle, lanes, M):

@@ -16,6 +16,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import oracle as orc  # noqa: E402
 from sccav_cbf_amd.batched import BatchedCBF, planes_to_tiled  # noqa: E402
 from tests import parity  # noqa: E402
+from tests.test_gpu_parity import _near_feasibility_boundary  # noqa: E402
 
 DEV = torch.device("cuda", 0)
 
@@ -55,7 +56,7 @@ def main():
     args = ap.parse_args()
     rng = np.random.default_rng(args.seed)
     orc.build()
-    misses, total64, total32, st_mism32 = 0, 0, 0, 0
+    misses, total64, total32, st_mism32, worst32 = 0, 0, 0, 0, 0.0
     for case in range(args.cases):
         M = int(rng.choice([1, 2, 3, 4, 7, 8, 12, 16, 17, 24, 32, 48, 64]))
         A = args.agents + int(rng.integers(0, 70))
@@ -63,13 +64,18 @@ def main():
         q = rng.normal(size=(2, 2))
         R = q @ q.T + 0.3 * np.eye(2)
         alpha = float(rng.choice([0.3, 1.0, 4.0]))
-        dyn = str(rng.choice(["dbm", "kbm"]))
+        dyn = str(rng.choice(["dbm", "kbm", "dum", "sadbm"]))
         slip = bool(rng.integers(0, 2))
         per_agent = bool(rng.integers(0, 2))
         tiled = bool(rng.integers(0, 2))
         lanes = int(rng.choice([0, 1, 2, 4, 8, 16, 64]))
         if lanes not in (0, 64) and M > 16 * lanes:
             lanes = 0
+        if dyn in ("dum", "sadbm"):     # these models run with 4 or 16 lanes per QP
+            lanes = lanes if lanes in (0, 16) or (lanes == 4 and M <= 64) else 0
+        sa_dt = float(rng.choice([0.02, 0.1]))
+        sa_slip = np.stack([rng.uniform(-0.3, 0.3, A), rng.uniform(-0.3, 0.3, A)], axis=1)
+        cone_beta = bool(rng.integers(0, 2))
         if dyn == "kbm":
             u_ref[:, 0] = np.abs(u_ref[:, 0]) + 2.0
         ty = kinds
@@ -81,19 +87,52 @@ def main():
             flags |= orc.FLAG_TYPE_PER_AGENT
         if args.only >= 0 and case != args.only:
             continue
-        p = orc.make_params(alpha=alpha, R=R.reshape(-1), flags=flags, dynamics=0 if dyn == "dbm" else 1)
-        uo, so, ro = orc.solve_batch(p, state, u_ref, obs, ty, want_rows=True)
+        dcode = {"dbm": 0, "kbm": 1, "dum": 2, "sadbm": 3}[dyn]
+        if dyn in ("dum", "sadbm"):
+            slip = dyn == "dum"          # DUM has no steering maps; SADBM is judged in QP coordinates below
+            flags &= ~orc.FLAG_SLIP_IO
+        if dyn == "sadbm" and cone_beta:
+            flags |= orc.FLAG_CONE_BETA_STATE
+        p = orc.make_params(alpha=alpha, R=R.reshape(-1), flags=flags, dynamics=dcode)
+        u_given = u_ref
+        if dyn == "sadbm":
+            slo = sa_slip.copy()
+            uo, so, ro = orc.solve_sa_batch(p, sa_dt, state, slo, u_given, obs, ty, want_rows=True)
+            # QP coordinates [a, d(beta)/dt]: nominal input and answers
+            beta_ref = np.arctan2(1.45 * np.tan(u_given[:, 1]), 2.9)
+            u_ref = np.stack([u_given[:, 0], (beta_ref - sa_slip[:, 1]) / sa_dt], axis=1)
+            uo = np.stack([uo[:, 0], (slo[:, 0] - sa_slip[:, 0]) / sa_dt], axis=1)
+            uo[so == 2] = u_ref[so == 2]
+        else:
+            uo, so, ro = orc.solve_batch(p, state, u_ref, obs, ty, want_rows=True)
+        # the rows of the same data rounded to fp32 (what the fp32 kernels are given): how far rounding the
+        # inputs alone moves a row measures how ill-conditioned that row is in single precision
+        r32 = lambda v: v.astype(np.float32).astype(np.float64)       # noqa: E731
+        if dyn == "sadbm":
+            _, _, ro32 = orc.solve_sa_batch(p, sa_dt, r32(state), r32(sa_slip), r32(u_given), r32(obs), ty, want_rows=True)
+        else:
+            _, _, ro32 = orc.solve_batch(p, r32(state), r32(u_given), r32(obs), ty, want_rows=True)
         tag = "case %d M=%d A=%d %s slip=%d per_agent=%d tiled=%d lanes=%d alpha=%g" % (
             case, M, A, dyn, slip, per_agent, tiled, lanes, alpha)
         for dtype in (torch.float64, torch.float32):
-            f = BatchedCBF(alpha=alpha, R=R, dynamics=dyn, slip_io=slip, lanes_per_qp=lanes)
+            f = BatchedCBF(alpha=alpha, R=R, dynamics=dyn, slip_io=slip and dyn in ("dbm", "kbm"), lanes_per_qp=lanes)
             tobs = torch.from_numpy(obs).to(DEV).to(dtype)
             if tiled:
                 tobs = planes_to_tiled(tobs)
-            u, st, rg = f.solve(torch.from_numpy(state).to(DEV).to(dtype), torch.from_numpy(u_ref).to(DEV).to(dtype),
-                                tobs, torch.from_numpy(ty).to(DEV), want_rows=True)
+            kw = {}
+            if dyn == "sadbm":
+                kw = dict(slip=torch.from_numpy(sa_slip).to(DEV).to(dtype), dt=sa_dt, cone_beta_state=cone_beta)
+            u, st, rg = f.solve(torch.from_numpy(state).to(DEV).to(dtype), torch.from_numpy(u_given).to(DEV).to(dtype),
+                                tobs, torch.from_numpy(ty).to(DEV), want_rows=True, **kw)
             torch.cuda.synchronize()
             u, st, rg = u.double().cpu().numpy(), st.cpu().numpy(), rg.double().cpu().numpy()
+            if dyn == "sadbm":
+                slg = kw["slip"].double().cpu().numpy()
+                if dtype == torch.float64 and (np.abs(slg - slo).max() > 1e-7 * (1 + np.abs(slo).max())):
+                    misses += 1
+                    print("MISS f64 slip state %s: %.3g" % (tag, np.abs(slg - slo).max()), flush=True)
+                u = np.stack([u[:, 0], (slg[:, 0] - sa_slip[:, 0]) / sa_dt], axis=1)
+                u[st == 2] = u_ref[st == 2]
             if args.only >= 0 and dtype == torch.float32:
                 np.set_printoptions(linewidth=200, precision=6)
                 scale = np.maximum(1.0, np.hypot(uo[:, 0], uo[:, 1]))
@@ -106,46 +145,86 @@ def main():
                     for m in np.argsort(rel)[::-1][:3]:
                         print("    slot %d kind %d rel row error %.3g: gpu %s oracle %s slot %s" % (m, kk[m], rel[m], rg[m, a], ro[m, a], obs[m, :, a, :].reshape(-1)))
             scale = np.maximum(1.0, np.hypot(uo[:, 0], uo[:, 1]))
-            well = np.abs(uo[:, 1]) < 1.2 if not slip else np.ones(A, bool)   # tan(delta) near pi/2
+            well = np.abs(uo[:, 1]) < 1.2 if not slip and dyn != "sadbm" else np.ones(A, bool)   # tan(delta) near pi/2
             if dtype == torch.float64:
                 total64 += A
                 bad = (st != so)
                 du = (np.abs(u - uo).max(axis=1) / scale)
-                bad |= (so == 0) & well & (du > 1e-6)
+                # in steering coordinates a slip angle of thousands of radians (a vertex far away on nearly
+                # parallel rows) comes back through tan / atan2: judged only where the answer is near the input
+                near = np.abs(uo[:, 0] - u_ref[:, 0]) <= 1e2
+                bad |= (so == 0) & well & near & (du > 1e-6)
                 if bad.any():
                     misses += 1
                     a = int(np.argmax(bad))
                     print("MISS f64 %s: %d agents, e.g. agent %d status %d/%d du %.3g" % (tag, bad.sum(), a, st[a], so[a], du[a]),
                           flush=True)
+                    if args.only >= 0:
+                        np.set_printoptions(linewidth=200, precision=12)
+                        print("  u gpu %s oracle %s u_ref %s state %s" % (u[a], uo[a], u_ref[a], state[a]))
+                        lhs = ro[:, a, 0] * uo[a, 0] + ro[:, a, 1] * np.arctan2(1.45 * np.tan(uo[a, 1]), 2.9)
+                        print("  oracle rows (a0, a1, b, h) and slack at the oracle's answer (beta coordinates):")
+                        for m in range(M):
+                            print("   ", ro[m, a], lhs[m] - ro[m, a, 2], " gpu row", rg[m, a])
             else:
                 total32 += A
                 st_mism32 += int((st != so).sum())
-                # a verdict may differ where the optimum (fp64's or fp32's) lies 1e3 and more from the nominal
-                # input: two nearly parallel rows (for DBM every row without dh/dv has the normal (0, a1)), whose
-                # vertex fp32 cannot place; anything else is a miss
-                far = ((so == 0) & (np.abs(uo - u_ref).max(axis=1) > 1e3)) | ((st == 0) & (np.abs(u - u_ref).max(axis=1) > 1e3))
-                unexplained = (st != so) & ~far & ((st == 2) | (so == 2) | slip)
-                if unexplained.sum() > max(1, A // 2000):
+                # stage 1, rows: every element against the magnitude of its row; allowed: 1e-3, or 16 times
+                # what rounding the inputs to fp32 does to the exact row (a cone seen at nearly the agent's own
+                # velocity divides by the small relative speed)
+                rscale = np.abs(ro32).max(axis=2, keepdims=True) + 1.0
+                relm = (np.abs(rg - ro32) / rscale).max(axis=2) - 16.0 * (np.abs(ro - ro32) / rscale).max(axis=2)
+                rel = relm.max()
+                if rel > 1e-3:
                     misses += 1
-                    print("MISS f32 status %s: %d of %d agents differ without a far vertex" % (tag, unexplained.sum(), A), flush=True)
-                if not slip:
-                    continue    # conditioning is judged in QP coordinates below
+                    m_, a_ = np.unravel_index(np.argmax(relm), relm.shape)
+                    print("MISS f32 rows %s: %.3g at slot %d (kind %d) agent %d\n   gpu %s\n   oracle %s\n   slot %s state %s"
+                          % (tag, rel, m_, (ty[m_, a_] if per_agent else ty[m_]), a_, rg[m_, a_], ro[m_, a_],
+                             obs[m_, :, a_, :].reshape(-1), state[a_]), flush=True)
+                if ((st == 2) != (so == 2)).any():
+                    misses += 1
+                    print("MISS f32 non-finite verdicts differ %s" % tag, flush=True)
+                if not slip and dyn != "sadbm":
+                    continue    # the QP stage is judged in QP coordinates
+                # stage 2, the QP on the rows the GPU itself formed, against the exact optimum of those rows.
+                # A verdict may differ where the optimum (either one) lies 1e3 and more from the nominal input
+                # (two nearly parallel rows: for DBM every row without dh/dv has the normal (0, a1)) or where
+                # the rows are within 1e-3 (relative) of the boundary of feasibility.
+                un = u_ref.astype(np.float32).astype(np.float64)
+                pq = orc.make_params(R=R.reshape(-1))
+                rq = np.ascontiguousarray(rg)
+                uq, sq = orc.qp_batch(pq, rq, un)
+                far = ((sq == 0) & (np.abs(uq - un).max(axis=1) > 1e3)) | ((st == 0) & (np.abs(u - un).max(axis=1) > 1e3))
+                idx = np.where((st != sq) & (st != 2) & ~far)[0]
+                if idx.size and not all(_near_feasibility_boundary(idx[k:k + 1], sq, rq, un, R) for k in range(idx.size)):
+                    misses += 1
+                    print("MISS f32 status %s: %d of %d agents differ from the exact QP on the same rows without a far "
+                          "vertex or a feasibility margin below 1e-3" % (tag, idx.size, A), flush=True)
+                    if args.only >= 0:
+                        np.set_printoptions(linewidth=200, precision=9)
+                        for a_ in idx:
+                            print("  agent %d status gpu %d exact %d oracle %d; u gpu %s exact %s nominal %s" % (
+                                a_, st[a_], sq[a_], so[a_], u[a_], uq[a_], un[a_]))
+                            for m_ in range(M):
+                                print("     row", rq[m_, a_], " oracle row", ro[m_, a_])
+                both = (st == 0) & (sq == 0)
+                det = parity.active_det(uq, rq)
+                ok = both & (det >= 1e-2) & (np.abs(uq - un).max(axis=1) <= 50)
+                dq = np.abs(u - uq).max(axis=1) / np.maximum(1.0, np.hypot(uq[:, 0], uq[:, 1]))
+                if ok.any() and dq[ok].max() > 1e-3:
+                    misses += 1
+                    a = int(np.argmax(np.where(ok, dq, 0)))
+                    print("MISS f32 qp %s: agent %d du %.3g det %.3g" % (tag, a, dq[a], det[a]), flush=True)
+                # for the record: distance to the oracle's answer among well-conditioned optima
                 both = (st == 0) & (so == 0)
-                det = parity.active_det(uo, ro)
-                # well conditioned: the active pair is not a wedge and the answer is within 50 of the nominal input
-                # (a row with a tiny normal puts it far away and scales the row's rounding by the same factor)
-                ok = both & (det >= 1e-2) & (np.abs(uo - u_ref).max(axis=1) <= 50)
-                du = (np.abs(u - uo).max(axis=1) / scale)
-                # 5e-3: a cone row whose normal is the small remainder of cancelling terms (a few 1e-2 against
-                # products of several hundred) carries 1e-3 .. 4e-3 relative error in fp32, and so does its answer
-                if ok.any() and du[ok].max() > 5e-3:
-                    misses += 1
-                    a = int(np.argmax(np.where(ok, du, 0)))
-                    print("MISS f32 du %s: agent %d du %.3g det %.3g" % (tag, a, du[a], det[a]), flush=True)
+                ok = both & (parity.active_det(uo, ro) >= 1e-2) & (np.abs(uo - u_ref).max(axis=1) <= 50)
+                if ok.any():
+                    worst32 = max(worst32, float((np.abs(u - uo).max(axis=1) / scale)[ok].max()))
         if case % 50 == 49:
             print("... %d cases done, %d misses" % (case + 1, misses), flush=True)
-    print("cases %d: fp64 agents %d, fp32 agents %d (status differs on %d = %.2e), misses %d"
-          % (args.cases, total64, total32, st_mism32, st_mism32 / max(total32, 1), misses))
+    print("cases %d: fp64 agents %d, fp32 agents %d (status differs on %d = %.2e; worst |du| to the oracle among "
+          "well-conditioned optima %.3g), misses %d"
+          % (args.cases, total64, total32, st_mism32, st_mism32 / max(total32, 1), worst32, misses))
     sys.exit(1 if misses else 0)
 
 
