@@ -605,7 +605,11 @@ double orc_vehicle_step(double s[4], double acc, double delta, double lr, double
 
 static double orc_normalize_angle(double a)
 {
-    /* cbf/utils.py:93-106 */
+    /* cbf/utils.py:93-106 subtracts / adds 2 pi until the angle is in [-pi, pi]; an angle of
+     * many turns (a diverged state) would keep that loop busy for hours and an infinite one for
+     * ever: such angles are brought near first, non-finite ones returned as they are */
+    if (!isfinite(a)) return a;
+    if (fabs(a) > 64.0) a = remainder(a, 2.0 * M_PI);
     while (a > M_PI) a -= 2.0 * M_PI;
     while (a < -M_PI) a += 2.0 * M_PI;
     return a;

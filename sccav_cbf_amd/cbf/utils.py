@@ -5,7 +5,13 @@ ZERO_TOL = 1e-3  # reference cbf/utils.py:27
 
 
 def normalize_angle(angle):
-    """Angle wrapped to [-pi, pi] (reference cbf/utils.py:93-106)."""
+    """Angle wrapped to [-pi, pi] (reference cbf/utils.py:93-106, which subtracts / adds 2 pi in a
+    loop; here an angle of many turns is brought near first and a non-finite one returned as it
+    is, where that loop would run for hours or for ever)."""
+    if not math.isfinite(angle):
+        return angle
+    if abs(angle) > 64.0:
+        angle = math.remainder(angle, 2.0 * math.pi)
     while angle > math.pi:
         angle -= 2.0 * math.pi
     while angle < -math.pi:

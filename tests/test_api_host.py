@@ -158,3 +158,4 @@ def test_controllers():
     u2 = pid.control(2.0, 3.0)
     assert abs(u2 - (2.0 * 1 + 0.1 * 0.3 + 0.5 * (-10))) < 1e-12
     assert abs(normalize_angle(3 * np.pi) - np.pi) < 1e-12 and abs(vec_norm([3, 4]) - 5) < 1e-12
+    assert abs(normalize_angle(1e17)) <= np.pi and normalize_angle(float("inf")) == float("inf")   # and they return

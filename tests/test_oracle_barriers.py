@@ -218,3 +218,13 @@ def test_seeker_step_known_answer(oracle):
     assert np.allclose(obs[0, 1, 0, 0:2], [-1.8, -2.4], atol=1e-15)                    # cdot
     assert np.allclose(obs[1, 1, 0, 0:3], [np.arctan2(-4.0, -3.0), -1.8, -2.4], atol=1e-15)
     assert np.allclose(obs[2, 0, 0, 0:2], [1.0, 2.5], atol=1e-15)
+
+
+def test_nominal_of_a_diverged_state_returns(oracle):
+    """A heading of 1e17 rad or infinity (a rollout that diverged) must not keep the angle wrap busy."""
+    traj = np.array([[0.0, 0.0, 0.1, 5.0], [1.0, 0.0, 0.1, 5.0]])
+    state = np.array([[0.0, 1.0, 1e17, 3.0], [0.0, 1.0, np.inf, 3.0], [0.0, 1.0, 7.0, 3.0]])
+    u = oracle.nominal_batch(state, traj, np.zeros(3, dtype=np.int32))
+    assert np.isfinite(u[0]).all() and abs(u[0, 1]) <= np.pi + np.pi / 2 + 1e-9
+    assert not np.isfinite(u[1, 1])
+    assert np.isfinite(u[2]).all()

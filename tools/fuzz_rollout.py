@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""Randomised campaign for the fused rollout (fp64): sccbf_rollout_* in one launch against the three
+entry points launched tick by tick with the obstacles moved on the host by the oracle's restatements.
+Random slot kinds (ellipse, cone, lane, radial, empty), per-agent kinds, row counts 1..64, layouts,
+courses of 1..2048 way-points or none, PID state, way-point speeds, motion models, tick counts.
+
+    python tools/fuzz_rollout.py [--cases 200] [--seed 0]
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from fuzz_parity import random_case  # noqa: E402
+from oracle import oracle as orc  # noqa: E402
+from sccav_cbf_amd import _lib  # noqa: E402
+from sccav_cbf_amd.batched import BatchedCBF, planes_to_tiled  # noqa: E402
+from sccav_cbf_amd.nominal import BatchedNominal, ClosedLoop, vehicle_step  # noqa: E402
+
+DEV = torch.device("cuda", 0)
+
+
+def course(rng, N):
+    s = np.cumsum(rng.uniform(0.05, 0.5, N))
+    kind = int(rng.integers(0, 3))
+    if kind == 0:
+        x, y = s, 15.0 + 10 * np.sin(s / 15)
+    elif kind == 1:
+        x, y = 40 * np.sin(s / 20), 15 + 25 * np.sin(s / 13 + 0.3)
+    else:
+        x, y = s * np.cos(0.3), 15 + s * np.sin(0.3)
+    yaw = np.arctan2(np.gradient(y) if N > 1 else np.zeros(1), np.gradient(x) if N > 1 else np.ones(1))
+    return np.ascontiguousarray(np.stack([x, y, yaw, rng.uniform(3, 12, N)], axis=1))
+
+
+def advance(obs, ty, dt):
+    """SCCBF_MOTION_CONSTANT_VELOCITY on (M,2,A,4) planes with kinds (M,) or (M,A), in place."""
+    M, A = obs.shape[0], obs.shape[2]
+    k = np.broadcast_to(ty.reshape(M, -1), (M, A))
+    e, c, r = k == _lib.OBS_ELLIPSE, k == _lib.OBS_CONE, k == _lib.OBS_RADIAL
+    ang = obs[:, 0, :, 2] + obs[:, 1, :, 1]
+    dx = np.where(e, obs[:, 1, :, 1], np.where(c, obs[:, 0, :, 3] * np.cos(ang), np.where(r, obs[:, 1, :, 0], 0.0)))
+    dy = np.where(e, obs[:, 1, :, 2], np.where(c, obs[:, 0, :, 3] * np.sin(ang), np.where(r, obs[:, 1, :, 1], 0.0)))
+    obs[:, 0, :, 0] += dx * dt
+    obs[:, 0, :, 1] += dy * dt
+
+
+def seek(obs, ty, xy, dt, k, v_min):
+    """SCCBF_MOTION_SEEKER with per-agent kinds: the oracle's seeker step slot by slot."""
+    M, A = obs.shape[0], obs.shape[2]
+    kk = np.broadcast_to(ty.reshape(M, -1), (M, A))
+    for kind in (_lib.OBS_ELLIPSE, _lib.OBS_RADIAL, _lib.OBS_CONE):
+        tmp = obs.copy()
+        orc.seeker_step(tmp, np.full(M, kind, dtype=np.uint8), xy, dt, k=k, v_min=v_min)
+        sel = kk == kind
+        obs[:, 0][sel] = tmp[:, 0][sel]
+        obs[:, 1][sel] = tmp[:, 1][sel]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=200)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--only", type=int, default=-1)
+    args = ap.parse_args()
+    rng = np.random.default_rng(args.seed)
+    orc.build()
+    misses, agents, diverged = 0, 0, 0
+    for case in range(args.cases):
+        M = int(rng.choice([1, 2, 3, 4, 5, 8, 12, 16, 17, 31, 32, 33, 48, 64]))
+        A = int(rng.integers(1, 400))
+        T = int(rng.integers(1, 25))
+        state, _, obs, kinds = random_case(rng, A, M)
+        N = int(rng.choice([0, 1, 2, 33, 500, 2034, 2048]))
+        motion = str(rng.choice(["static", "constant_velocity", "seeker"]))
+        per_agent, tiled, pid, wps = (bool(rng.integers(0, 2)) for _ in range(4))
+        dt = float(rng.choice([0.05, 0.1]))
+        gain, vmin = float(rng.uniform(0, 0.5)), float(rng.uniform(0, 4))
+        ty = kinds
+        if per_agent:
+            ty = np.repeat(kinds[:, None], A, axis=1)
+            ty[rng.uniform(size=ty.shape) < 0.2] = 255
+            ty = np.ascontiguousarray(ty)
+        traj = course(rng, N) if N else None
+        if traj is not None:      # put the agents near the course
+            at = rng.integers(0, N, A)
+            shift = np.stack([traj[at, 0] + rng.normal(0, 2, A), traj[at, 1] + rng.normal(0, 2, A)], axis=1) - state[:, :2]
+            state[:, :2] += shift
+            keep = (np.broadcast_to(ty.reshape(M, -1), (M, A)) != _lib.OBS_LANE)
+            obs[:, 0, :, 0] += np.where(keep, shift[None, :, 0], 0.0)
+            obs[:, 0, :, 1] += np.where(keep, shift[None, :, 1], 0.0)
+            state[:, 2] = traj[at, 2] + rng.normal(0, 0.3, A)
+        if args.only >= 0 and case != args.only:
+            continue
+        tag = "case %d A=%d M=%d T=%d N=%d %s per_agent=%d tiled=%d pid=%d wps=%d dt=%g" % (
+            case, A, M, T, N, motion, per_agent, tiled, pid, wps, dt)
+
+        def make(state=state, obs=obs):
+            tobs = torch.from_numpy(obs).to(DEV)
+            nom = BatchedNominal(axle=2.9, k=0.5, ks=0.01, kp=1.0, ki=0.2, kd=0.02, dt=dt, waypoint_speed=wps) if N else None
+            return ClosedLoop(BatchedCBF(alpha=1.0, R=np.diag([0.5, 0.5])), nom,
+                              torch.from_numpy(traj).to(DEV) if N else None, torch.from_numpy(state.copy()).to(DEV),
+                              planes_to_tiled(tobs) if tiled else tobs, torch.from_numpy(ty).to(DEV),
+                              dt=dt, use_pid_state=pid and N > 0)
+        def tick_by_tick(la, obs=obs):
+            host = obs.copy()
+            tr = []
+            for _ in range(T):
+                if N:
+                    la.nominal.control(la.state, la.traj, la.target_idx, la.pid_state, u_ref=la.u_ref)
+                u, st = la.cbf.solve(la.state, la.u_ref, la.obs, la.obs_type, u_out=la.u, status=la.status)
+                vehicle_step(la.state, la.u, lr=1.45, lf=1.45, max_steer=la.max_steer, dt=dt, beta_out=la.beta)
+                tr.append(torch.cat([u, la.beta[:, None], st.double()[:, None]], dim=1).clone())
+                if motion == "constant_velocity":
+                    advance(host, ty, dt)
+                elif motion == "seeker":
+                    seek(host, ty, la.state[:, 0:2].cpu().numpy(), dt, gain, vmin)
+                if motion != "static":
+                    tobs = torch.from_numpy(host).to(DEV)
+                    la.obs = planes_to_tiled(tobs) if tiled else tobs
+            return torch.stack(tr), host
+        la = make()
+        tr, host = tick_by_tick(la)
+        # how sensitive each closed loop is: the same ticks from data one fp64 ulp away (two trials)
+        prng = np.random.default_rng([args.seed, case])
+        ulp = lambda v: np.nextafter(v, np.where(prng.integers(0, 2, v.shape) == 1, np.inf, -np.inf))   # noqa: E731
+        probes = []
+        for _ in range(2):
+            o2 = ulp(obs)
+            probes.append(tick_by_tick(make(ulp(state), o2), o2)[0])
+        lb = make()
+        out = lb.rollout(T, motion=motion, trace=True, seek_gain=gain, seek_v_min=vmin)
+        torch.cuda.synchronize()
+        agents += A
+        same = (out["trace"][:, :, 3] == tr[:, :, 3]).all(dim=0)
+        # an agent driven to inputs of 1e4 and more (a vertex on nearly parallel rows) amplifies the last
+        # bits within a few ticks: its history is compared up to the tick before it first gets there
+        calm = (tr[:, :, :2].abs().amax(dim=2) < 1e3).cumprod(dim=0).bool()            # (T, A)
+        d = ((out["trace"][:, :, :3] - tr[:, :, :3]).abs().amax(dim=2) / (1 + tr[:, :, :2].abs().amax(dim=2)))
+        # ... and while an ulp on the data has not grown beyond 1e-12 (sliding contact with a seeker,
+        # steering that flips sign from tick to tick: such loops multiply a difference by 50 and more per tick)
+        for tr2 in probes:
+            e = ((tr2[:, :, :3] - tr[:, :, :3]).abs().amax(dim=2) / (1 + tr[:, :, :2].abs().amax(dim=2)))
+            calm &= (torch.cummax(e, dim=0).values < 1e-12) & (tr2[:, :, 3] == tr[:, :, 3]).cumprod(dim=0).bool()
+        diverged += int((~calm[-1]).sum())
+        dmax = float(torch.where(calm, d, torch.zeros_like(d)).max())
+        smis = int(((out["trace"][:, :, 3] != tr[:, :, 3]) & calm).sum())
+        ok_state = calm[-1]
+        ds = float(((lb.state - la.state).abs().amax(dim=1) / (1 + la.state.abs().amax(dim=1)))[ok_state].max()) if ok_state.any() else 0.0
+        di = int((lb.target_idx - la.target_idx)[ok_state].abs().max()) if N and ok_state.any() else 0
+        if dmax > 1e-6 or smis > 0 or ds > 1e-6 or di > 0:
+            misses += 1
+            print("MISS %s: trace %.3g, status differs on %d agent-ticks, state %.3g, target index %d" % (tag, dmax, smis, ds, di),
+                  flush=True)
+        if args.only >= 0:
+            # third opinion: the whole loop on the host by the oracle
+            so_, ob_ = state.copy(), obs.copy()
+            tgt = np.zeros(A, dtype=np.int32)
+            ps = np.zeros((A, 2)) if (pid and N) else None
+            prm = orc.make_params(alpha=1.0, R=(0.5, 0, 0, 0.5), flags=orc.FLAG_TYPE_PER_AGENT if per_agent else 0)
+            tro = np.zeros((T, A, 4))
+            for t in range(T):
+                ur = np.zeros((A, 2))
+                if N:
+                    ur = orc.nominal_batch(so_, traj, tgt, ps, axle=2.9, k=0.5, ks=0.01, kp=1.0, ki=0.2, kd=0.02, dt=dt,
+                                           target_speed=30 / 3.6) if not wps else None
+                if ur is None:
+                    raise SystemExit("the host loop does not restate way-point speeds")
+                uo, sto, _ = orc.solve_batch(prm, so_, ur, ob_, ty)
+                be = orc.vehicle_step_batch(so_, uo, 1.45, 1.45, np.radians(30.0), dt)
+                tro[t, :, :2], tro[t, :, 2], tro[t, :, 3] = uo, be, sto
+                if motion == "constant_velocity":
+                    advance(ob_, ty, dt)
+                elif motion == "seeker":
+                    seek(ob_, ty, so_[:, :2].copy(), dt, gain, vmin)
+            for name, tt in (("rollout", out["trace"].cpu().numpy()), ("ticks", tr.cpu().numpy())):
+                e = np.abs(tt[:, :, :3] - tro[:, :, :3]).max(axis=2) / (1 + np.abs(tro[:, :, :2]).max(axis=2))
+                print("%s against the host loop: per-tick worst %s" % (name, np.array2string(e.max(axis=1), precision=2)))
+            dd = torch.where(calm, d, torch.zeros_like(d))
+            a_ = int(dd.amax(dim=0).argmax())
+            t_ = int((dd[:, a_] > 1e-9).float().argmax())
+            np.set_printoptions(linewidth=200, precision=9)
+            print("agent %d first differs at tick %d of %d" % (a_, t_, T))
+            for t in range(max(0, t_ - 1), min(T, t_ + 3)):
+                print("  tick %d rollout %s\n          ticks   %s" % (t, out["trace"][t, a_].cpu().numpy(), tr[t, a_].cpu().numpy()))
+            kk = ty[:, a_] if per_agent else ty
+            print("  kinds", kk, " final host slots of the agent:")
+            for m in range(M):
+                print("    ", host[m, :, a_, :].reshape(-1), " dist to ego %.4g" % np.hypot(*(host[m, 0, a_, :2] - la.state[a_, :2].cpu().numpy())))
+        if case % 50 == 49:
+            print("... %d cases done, %d misses" % (case + 1, misses), flush=True)
+    print("cases %d, agents %d (%d left the range where an ulp on the data stays below 1e-12), misses %d" % (args.cases, agents, diverged, misses))
+    sys.exit(1 if misses else 0)
+
+
+if __name__ == "__main__":
+    main()
