@@ -22,6 +22,8 @@ constexpr int kTrajChunk = 2048;  // way-points staged in LDS per pass
 constexpr int kSub = 32;          // way-points per bounding box
 constexpr int kSubs = kTrajChunk / kSub;
 constexpr int kSubStride = kSub + 1;  // odd stride: groups scanning different runs hit different banks
+constexpr int kSup = 4;               // runs per outer bounding box (128 way-points)
+constexpr int kSups = kSubs / kSup;
 constexpr int kNomLanes = 4;          // lanes per agent in the nominal and rollout kernels
 constexpr int kNomBlock = 1024;       // threads per workgroup of the nominal kernel: 256 agents share one staging
 
@@ -35,11 +37,12 @@ template <typename T> __device__ inline T wrap_pi_(T a)
     return a;
 }
 
-// One pass (up to 2048 way-points) of the course in LDS: coordinates in runs of 32 and the
-// bounding box of every run (four extra empty boxes for the four-at-a-time walk).
+// One pass (up to 2048 way-points) of the course in LDS: coordinates in runs of 32, the
+// bounding box of every run and the box of every four runs.
 template <typename T> struct CoursePass {
     T x[kSubs * kSubStride], y[kSubs * kSubStride];
-    T x0[kSubs + kNomLanes], x1[kSubs + kNomLanes], y0[kSubs + kNomLanes], y1[kSubs + kNomLanes];
+    T x0[kSubs], x1[kSubs], y0[kSubs], y1[kSubs];
+    T X0[kSups], X1[kSups], Y0[kSups], Y1[kSups];
 };
 
 // Every thread of a BLOCK-thread workgroup takes 2048 / BLOCK consecutive way-points of the
@@ -52,7 +55,7 @@ __device__ inline void stage_course_(CoursePass<T>& c, const typename VT<T>::v4*
     using v2 = typename VT<T>::v2;
     constexpr int kPer = kTrajChunk / BLOCK;  // way-points per thread
     constexpr int kThr = kSub / kPer;         // threads per run
-    static_assert(kPer * BLOCK == kTrajChunk && kThr * kPer == kSub && kThr <= 64, "block size");
+    static_assert(kPer * BLOCK == kTrajChunk && kThr * kPer == kSub && kThr * kSup <= 64, "block size");
     T x0 = INFINITY, x1 = -INFINITY, y0 = INFINITY, y1 = -INFINITY;
     const int r = threadIdx.x / kThr, j0 = (threadIdx.x % kThr) * kPer;
 #pragma unroll
@@ -76,34 +79,65 @@ __device__ inline void stage_course_(CoursePass<T>& c, const typename VT<T>::v4*
     if (threadIdx.x % kThr == 0) {
         c.x0[r] = x0; c.x1[r] = x1; c.y0[r] = y0; c.y1[r] = y1;
     }
-    if (threadIdx.x < kNomLanes) {
-        c.x0[kSubs + threadIdx.x] = INFINITY; c.x1[kSubs + threadIdx.x] = -INFINITY;
-        c.y0[kSubs + threadIdx.x] = INFINITY; c.y1[kSubs + threadIdx.x] = -INFINITY;
+    // the four runs of an outer box sit in kSup * kThr neighbouring lanes of one wavefront
+#pragma unroll
+    for (int m = kThr; m < kThr * kSup; m *= 2) {
+        x0 = min_(x0, __shfl_xor(x0, m, 64)); x1 = max_(x1, __shfl_xor(x1, m, 64));
+        y0 = min_(y0, __shfl_xor(y0, m, 64)); y1 = max_(y1, __shfl_xor(y1, m, 64));
+    }
+    if (threadIdx.x % (kThr * kSup) == 0) {
+        c.X0[r / kSup] = x0; c.X1[r / kSup] = x1; c.Y0[r / kSup] = y0; c.Y1[r / kSup] = y1;
     }
 }
 
-// Nearest way-point of one staged pass to (fx, fy), by the four lanes of a group: they step
-// through the boxes four at a time and scan (eight way-points each) only the runs whose box
-// is not farther than lim, the best squared distance known so far (on entry: any upper bound
-// of the answer).  best / bi: this lane's nearest way-point so far (strict "<" in index
-// order, so the first index wins a tie).  Every group walks its own list of runs: a wavefront
-// pays for the longest list among its groups, not for their union.
+// Squared distance from (fx, fy) to a bounding box (infinite for the box of an empty run).
+template <typename T> __device__ inline T box_d2_(T x0, T x1, T y0, T y1, T fx, T fy)
+{
+    const T dx = max_(max_(x0 - fx, fx - x1), T(0));
+    const T dy = max_(max_(y0 - fy, fy - y1), T(0));
+    return dx * dx + dy * dy;
+}
+
+// Nearest way-point of one staged pass to (fx, fy), by the four lanes of a group.  lim is the
+// best squared distance known so far (on entry: any upper bound of the answer).  First the group
+// lists the runs that can hold the answer: the outer boxes not farther than lim (four per lane and
+// step), then the run boxes inside those (one per lane and outer box); then it scans the listed
+// runs in index order, eight way-points per lane, tightening lim as it goes and skipping a run
+// whose box has fallen behind the bound.  best / bi: this lane's nearest way-point so far (strict
+// "<" in index order, so the first index wins a tie).  Every group works through its own list and
+// the groups of a wavefront scan their k-th runs together: a wavefront pays for the longest list
+// among its groups, not for their union.
 template <typename T>
 __device__ inline void nearest_in_pass_(const CoursePass<T>& c, T fx, T fy, int g, int base, int runs,
                                         T& lim, T& best, int& bi)
 {
     constexpr int G = kNomLanes;
-    for (int r = 0; r < runs;) {  // r and lim are the same in the four lanes of a group
-        // lane g looks at the box of run r + g (infinitely far when the run is empty)
-        const T dx = max_(max_(c.x0[r + g] - fx, fx - c.x1[r + g]), T(0));
-        const T dy = max_(max_(c.y0[r + g] - fy, fy - c.y1[r + g]), T(0));
-        // (a few ulps of slack: the box distance and the way-point distance round independently)
-        const unsigned hit = group_or<G>((dx * dx + dy * dy <= lim * (T(1) + T(8) * Lim<T>::eps)) ? 1u << g : 0u);
-        if (hit == 0u) {
-            r += G;
-            continue;
-        }
-        r += __ffs(hit) - 1;  // the first run of the four that can hold the answer
+    static_assert(kSup == G && kSups <= 32 && kSubs <= 64, "one run box per lane inside an outer box; masks");
+    // (a few ulps of slack: the box distance and the way-point distance round independently)
+    constexpr T kSlack = T(1) + T(8) * Lim<T>::eps;
+    const int sups = (runs + kSup - 1) / kSup;
+    unsigned smask = 0u;
+    for (int i = 0; i * G < sups; ++i) {
+        const int so = i * G + g;  // boxes of runs past the end are empty: infinitely far
+        const T d2 = box_d2_(c.X0[so], c.X1[so], c.Y0[so], c.Y1[so], fx, fy);
+        smask |= (so < sups && d2 <= lim * kSlack) ? 1u << so : 0u;
+    }
+    smask = group_or<G>(smask);
+    unsigned rlo = 0u, rhi = 0u;  // bit r: run r is listed
+    while (smask != 0u) {
+        const int rr = (__ffs(smask) - 1) * kSup + g;
+        smask &= smask - 1u;
+        const bool in = box_d2_(c.x0[rr], c.x1[rr], c.y0[rr], c.y1[rr], fx, fy) <= lim * kSlack;
+        rlo |= (in && rr < 32) ? 1u << rr : 0u;
+        rhi |= (in && rr >= 32) ? 1u << (rr - 32) : 0u;
+    }
+    unsigned long long rmask = ((unsigned long long)group_or<G>(rhi) << 32) | group_or<G>(rlo);
+    const T listed = lim;  // rmask and lim are the same in the four lanes of a group
+    while (rmask != 0ull) {
+        const int r = __ffsll((long long)rmask) - 1;
+        rmask &= rmask - 1ull;
+        // the bound may have tightened since the boxes were tested
+        if (lim < listed && !(box_d2_(c.x0[r], c.x1[r], c.y0[r], c.y1[r], fx, fy) <= lim * kSlack)) continue;
 #pragma unroll
         for (int j = 0; j < kSub / G; ++j) {  // lane g: way-points 8 g .. 8 g + 7 of the run
             const int jj = g * (kSub / G) + j;
@@ -118,7 +152,6 @@ __device__ inline void nearest_in_pass_(const CoursePass<T>& c, T fx, T fy, int 
         m = min_(m, __shfl_xor(m, 1, 64));
         m = min_(m, __shfl_xor(m, 2, 64));
         lim = min_(lim, m);
-        ++r;
     }
 }
 
