@@ -163,7 +163,8 @@ int sccbf_solve_f64(const sccbf_params* p, int64_t A, int32_t M,
  *     Lf_h = dh/dx v cos(yaw + beta) + dh/dy v sin(yaw + beta) + dh/dyaw v sin(beta) / lr   (338-347, 398-405)
  * with dh/dbeta = dh/dyaw for a collision cone (obstacles.py:460-466) and 0 otherwise (124-125),
  * the QP, then beta += beta_dot* dt (421) and u_out = [a*, atan2((lf + lr) tan(beta), lr)] (430).
- * Status other than optimal: the nominal input is applied (beta += beta_dot_ref dt).
+ * SCCBF_STATUS_INFEASIBLE: the nominal input is applied (beta += beta_dot_ref dt, u_out from it).
+ * SCCBF_STATUS_NONFINITE: u_out = u_ref and the slip state is left as it was.
  * Cone slots read their own beta o[5] unless SCCBF_FLAG_CONE_BETA_STATE is set.
  * p->dynamics is ignored; SCCBF_FLAG_SLIP_IO is not allowed; 1 <= M <= 256 (an empty list raises
  * in the reference, 375-378); rows_out as in sccbf_solve_*.

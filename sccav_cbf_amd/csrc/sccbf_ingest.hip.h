@@ -66,11 +66,18 @@ template <typename T> struct FArgs {
 
 // PolyLane.fit_polynomial_curve, reference cbf/obstacles.py:715-773: the polynomial of the given
 // degree that minimises sum(((p(x_i) - y_i) / sigma_i)^2) (what scipy.optimize.curve_fit minimises
-// there for a model that is linear in its coefficients).  One thread per agent, fp64 throughout:
-// normal equations in t = (x - centre) / half-range (moments of |t| <= 1), Cholesky, then the
-// coefficients of the powers of x.  Points with sigma <= 0 or a non-finite value are skipped; if
-// the points do not determine the polynomial the coefficients are NaN (the filter then reports
-// the agent as non-finite).
+// there for a model that is linear in its coefficients).  One thread per agent, fp64 throughout.
+// The fit is built on the polynomials orthogonal under the points' own weighted inner product
+// (three-term recurrence in t = (x - centre) / half-range, one pass over the points per degree),
+// whose error grows with the condition of the problem and not with its square as the normal
+// equations' does.  The expansion coefficients are then corrected once from the residuals of the
+// first fit (a fixed point weighing 1e6 times its neighbours makes every level of the basis cancel
+// against it, which costs the first fit up to eleven digits and the corrected one none that
+// matter); the expansion gives the coefficients of the powers of x.  Points with
+// sigma <= 0 or a non-finite value are skipped; if the points do not determine the polynomial
+// (fewer distinct abscissae than coefficients: the next orthogonal polynomial vanishes on all of
+// them, up to its own rounding) the coefficients are NaN and the filter reports the agent as
+// non-finite.
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_lane_fit(const FArgs<T> p)
 {
@@ -92,52 +99,69 @@ __global__ __launch_bounds__(kBlock) void k_lane_fit(const FArgs<T> p)
     double hs = 0.5 * (xmax - xmin);
     if (!(hs > 0.0)) hs = 1.0;
     const double ihs = 1.0 / hs;
-    double S[7] = {0, 0, 0, 0, 0, 0, 0}, B[4] = {0, 0, 0, 0};
-    for (int k = 0; k < p.K; ++k) {
-        const double x = (double)p.px[(long long)k * p.A + a], y = (double)p.py[(long long)k * p.A + a];
-        const double sg = p.sigma ? (double)p.sigma[(long long)k * p.A + a] : 10.0;
-        if (!(sg > 0.0) || !isfinite(sg) || !isfinite(x) || !isfinite(y)) continue;
-        const double w = 1.0 / (sg * sg), t = (x - xc) * ihs;
-        double tj = w;
-#pragma unroll
-        for (int j = 0; j < 7; ++j) {
-            S[j] += tj;
-            if (j < 4) B[j] += tj * y;
-            tj *= t;
-        }
-    }
-    // Cholesky of G[i][j] = S[i + j], i, j < n
-    double Lc[4][4];
-    double d[4] = {0, 0, 0, 0};
+    // P_0 = 1, P_{j+1} = (t - al_j) P_j - be_j P_{j-1};  fit = sum_j cf_j P_j
+    double al[4] = {0, 0, 0, 0}, be[4] = {0, 0, 0, 0}, cf[4] = {0, 0, 0, 0}, nrm[4] = {1, 1, 1, 1};
+    double prev_norm = 1.0;
     bool ok = cnt >= n;
-    for (int i = 0; i < 4; ++i) {
-        if (i >= n) break;
-        for (int j = 0; j <= i; ++j) {
-            double s = S[i + j];
-            for (int q = 0; q < j; ++q) s -= Lc[i][q] * Lc[j][q];
-            if (i == j) {
-                if (!(s > 1e-13 * S[2 * i])) { ok = false; s = 1.0; }
-                Lc[i][i] = sqrt(s);
-            } else {
-                Lc[i][j] = s / Lc[j][j];
+    for (int j = 0; j < 4; ++j) {
+        if (j >= n) break;
+        double nn = 0.0, ta = 0.0, mm = 0.0;
+        for (int k = 0; k < p.K; ++k) {
+            const double x = (double)p.px[(long long)k * p.A + a], y = (double)p.py[(long long)k * p.A + a];
+            const double sg = p.sigma ? (double)p.sigma[(long long)k * p.A + a] : 10.0;
+            if (!(sg > 0.0) || !isfinite(sg) || !isfinite(x) || !isfinite(y)) continue;
+            const double w = 1.0 / (sg * sg), t = (x - xc) * ihs;
+            double pm = 0.0, pj = 1.0, qm = 0.0, qj = 1.0;  // P_{i-1}, P_i and bounds of the terms they sum
+            for (int i = 0; i < j; ++i) {
+                const double pn = (t - al[i]) * pj - be[i] * pm;
+                const double qn = (fabs(t) + fabs(al[i])) * qj + be[i] * qm;
+                pm = pj; pj = pn; qm = qj; qj = qn;
             }
+            nn += w * pj * pj;
+            ta += w * t * pj * pj;
+            mm += w * qj * qj;
         }
+        // P_j is its own rounding error on every point: the points have fewer than j + 1 distinct abscissae
+        if (!(nn > 1e-26 * mm)) { ok = false; nn = 1.0; }
+        al[j] = ta / nn;
+        be[j] = j ? nn / prev_norm : 0.0;
+        nrm[j] = nn;
+        prev_norm = nn;
     }
-    for (int i = 0; i < n; ++i) {  // L z = B
-        double s = B[i];
-        for (int q = 0; q < i; ++q) s -= Lc[i][q] * d[q];
-        d[i] = s / Lc[i][i];
+    // cf_j = <y, P_j> / <P_j, P_j>, then once more with the residuals y - fit in place of y
+    for (int pass = 0; pass < 2; ++pass) {
+        double g[4] = {0, 0, 0, 0};
+        for (int k = 0; k < p.K; ++k) {
+            const double x = (double)p.px[(long long)k * p.A + a], y = (double)p.py[(long long)k * p.A + a];
+            const double sg = p.sigma ? (double)p.sigma[(long long)k * p.A + a] : 10.0;
+            if (!(sg > 0.0) || !isfinite(sg) || !isfinite(x) || !isfinite(y)) continue;
+            const double w = 1.0 / (sg * sg), t = (x - xc) * ihs;
+            double P[4];
+            P[0] = 1.0;
+            P[1] = t - al[0];
+            P[2] = (t - al[1]) * P[1] - be[1] * P[0];
+            P[3] = (t - al[2]) * P[2] - be[2] * P[1];
+            double r = y;
+            for (int j = 0; j < 4; ++j) r -= j < n ? cf[j] * P[j] : 0.0;
+            for (int j = 0; j < 4; ++j) g[j] += w * r * P[j];
+        }
+        for (int j = 0; j < 4; ++j) cf[j] += j < n ? g[j] / nrm[j] : 0.0;
     }
-    for (int i = n - 1; i >= 0; --i) {  // L^T d = z
-        double s = d[i];
-        for (int q = i + 1; q < n; ++q) s -= Lc[q][i] * d[q];
-        d[i] = s / Lc[i][i];
+    // coefficients of the powers of t, then of x:  p(x) = sum_j d_j ((x - xc) / hs)^j
+    double Pm[4] = {0, 0, 0, 0}, Pj[4] = {1, 0, 0, 0}, d[4] = {0, 0, 0, 0};
+    for (int j = 0; j < 4; ++j) {
+        if (j >= n) break;
+        double Pn[4];
+        for (int k = 0; k < 4; ++k) {
+            d[k] += cf[j] * Pj[k];
+            Pn[k] = (k ? Pj[k - 1] : 0.0) - al[j] * Pj[k] - be[j] * Pm[k];
+        }
+        for (int k = 0; k < 4; ++k) { Pm[k] = Pj[k]; Pj[k] = Pn[k]; }
     }
-    // p(x) = sum_j d_j ((x - xc) / hs)^j  ->  coefficients of x^k
     double e[4], c[4] = {0, 0, 0, 0};
     double sc = 1.0;
     for (int j = 0; j < 4; ++j) {
-        e[j] = j < n ? d[j] * sc : 0.0;
+        e[j] = d[j] * sc;
         sc *= ihs;
     }
     const double binom[4][4] = {{1, 0, 0, 0}, {1, 1, 0, 0}, {1, 2, 1, 0}, {1, 3, 3, 1}};
