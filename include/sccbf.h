@@ -93,7 +93,9 @@ extern "C" {
 /* error codes */
 #define SCCBF_OK 0
 #define SCCBF_ERR_ARG (-1)         /* NULL pointer / negative size / A >= 2^31 / bad enum or flags */
-#define SCCBF_ERR_ROWS (-2)        /* M above SCCBF_MAX_ROWS */
+#define SCCBF_ERR_ROWS (-2)        /* M above SCCBF_MAX_ROWS, or above the limit stated at the entry point
+                                      (256 rows for the DUM / SADBM models, 64 slots and 2048 way-points
+                                      for the rollout) */
 #define SCCBF_ERR_WEIGHT (-3)      /* R not symmetric positive definite */
 #define SCCBF_ERR_LAUNCH (-4)      /* hipLaunch failed */
 #define SCCBF_ERR_VARIANT (-5)     /* lanes_per_qp cannot hold M rows */

@@ -433,10 +433,10 @@ const char* sccbf_strerror(int code)
     switch (code) {
     case SCCBF_OK: return "ok";
     case SCCBF_ERR_ARG: return "invalid argument (null pointer, negative size or bad enum)";
-    case SCCBF_ERR_ROWS: return "too many constraint rows (M > SCCBF_MAX_ROWS)";
+    case SCCBF_ERR_ROWS: return "too many rows or way-points for this entry point (see its limits in sccbf.h)";
     case SCCBF_ERR_WEIGHT: return "QP weight R is not symmetric positive definite";
     case SCCBF_ERR_LAUNCH: return "kernel launch failed";
-    case SCCBF_ERR_VARIANT: return "lanes_per_qp cannot hold M rows (use 0 or 64)";
+    case SCCBF_ERR_VARIANT: return "lanes_per_qp cannot hold M rows or is not offered for this model (use 0)";
     case SCCBF_ERR_NO_DEVICE: return "no usable HIP device";
     default: return "unknown error";
     }

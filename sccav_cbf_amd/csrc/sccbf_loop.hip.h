@@ -343,7 +343,8 @@ __device__ inline void seek_slot_(int type, typename VT<T>::v4& oa, typename VT<
 // through the per-wavefront LDS table of the 4-lane filter kernel.  No HBM traffic inside the
 // loop except the optional trace.
 template <typename T, int RPL>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SCCBF_ROLLOUT_WAVES, SCCBF_ROLLOUT_WAVES)))
+__global__ __launch_bounds__(kBlock)
+__attribute__((amdgpu_waves_per_eu((sizeof(T) == 4 && RPL <= 4) ? SCCBF_ROLLOUT_WAVES : 1, SCCBF_ROLLOUT_WAVES)))
 void k_rollout(const RArgs<T> a)
 {
     using v4 = typename VT<T>::v4;
