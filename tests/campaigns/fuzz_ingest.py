@@ -3,7 +3,7 @@
 against the oracle: random point counts, degrees, weights with fixed points, skipped points,
 exact duplicates, too few points; random boxes, kinds and layouts.
 
-    python tools/fuzz_ingest.py [--cases 300] [--seed 0]
+    python tests/campaigns/fuzz_ingest.py [--cases 300] [--seed 0]
 """
 import argparse
 import os
@@ -12,7 +12,7 @@ import sys
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import oracle as orc  # noqa: E402
 from sccav_cbf_amd.batched import planes_to_tiled  # noqa: E402
 from sccav_cbf_amd.ingest import ingest_bbox, lane_fit  # noqa: E402

@@ -9,7 +9,7 @@ import sys
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import oracle as orc  # noqa: E402
 from sccav_cbf_amd.nominal import BatchedNominal  # noqa: E402
 

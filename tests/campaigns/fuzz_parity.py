@@ -3,7 +3,7 @@
 cone, lane, radial, empty), row counts, weights, dynamics, layouts and kernel variants against the
 fp64 oracle.  Prints one line per case that misses the bar and a summary; exit status 1 on a miss.
 
-    python tools/fuzz_parity.py [--cases 300] [--seed 0]
+    python tests/campaigns/fuzz_parity.py [--cases 300] [--seed 0]
 """
 import argparse
 import os
@@ -12,7 +12,7 @@ import sys
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import oracle as orc  # noqa: E402
 from sccav_cbf_amd.batched import BatchedCBF, planes_to_tiled  # noqa: E402
 from tests import parity  # noqa: E402

@@ -4,7 +4,7 @@ entry points launched tick by tick with the obstacles moved on the host by the o
 Random slot kinds (ellipse, cone, lane, radial, empty), per-agent kinds, row counts 1..64, layouts,
 courses of 1..2048 way-points or none, PID state, way-point speeds, motion models, tick counts.
 
-    python tools/fuzz_rollout.py [--cases 200] [--seed 0]
+    python tests/campaigns/fuzz_rollout.py [--cases 200] [--seed 0]
 """
 import argparse
 import os
@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from fuzz_parity import random_case  # noqa: E402
 from oracle import oracle as orc  # noqa: E402
 from sccav_cbf_amd import _lib  # noqa: E402

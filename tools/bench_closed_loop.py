@@ -10,8 +10,8 @@ import sys
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from oracle import replay  # noqa: E402  (course fixture only)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 from sccav_cbf_amd import scenarios  # noqa: E402
 from sccav_cbf_amd.batched import BatchedCBF, planes_to_tiled  # noqa: E402
 from sccav_cbf_amd.nominal import BatchedNominal, ClosedLoop, vehicle_step  # noqa: E402
@@ -39,7 +39,8 @@ def main():
     dev = torch.device("cuda", 0)
     dt = torch.float32 if args.dtype == "f32" else torch.float64
     A = args.agents
-    cx, cy, cyaw = replay.load_course()
+    course = np.load(os.path.join(ROOT, "tests", "golden", "sce_course.npz"))   # the shipped 2034-point course
+    cx, cy, cyaw = course["cx"], course["cy"], course["cyaw"]
     traj = torch.from_numpy(np.stack([cx, cy, cyaw, np.full_like(cx, 30 / 3.6)], axis=1)).to(dt).to(dev)
     w = scenarios.config4(A=A, seed=1)
     # agents start within a few metres of the course (the closed-loop use case); the obstacles of the
