@@ -103,7 +103,10 @@ class ClosedLoop:
     runs: move them between ticks (or inside the captured region) with ordinary tensor ops.
 
     nominal=None, traj=None: no course, the nominal input is (0, 0) on every tick (the stationary
-    ego of test_scripts/radial_dynamic_obstacles.py:444)."""
+    ego of test_scripts/radial_dynamic_obstacles.py:444).  With a steer-rate filter
+    (BatchedCBF(dynamics="sadbm")) tick() keeps the slip state in self.slip (beta, beta_ref_last) and
+    every cone follows the filter's beta, as reference cbf/cbf.py:424-427 leaves them; rollout() is
+    for the DBM filter."""
 
     def __init__(self, cbf: BatchedCBF, nominal: BatchedNominal, traj, state, obs, obs_type,
                  max_steer=np.radians(30.0), dt=0.1, use_pid_state=False):
@@ -119,6 +122,8 @@ class ClosedLoop:
         self.u = torch.empty((A, 2), dtype=ty, device=dev)
         self.status = torch.empty((A,), dtype=torch.int32, device=dev)
         self.beta = torch.empty((A,), dtype=ty, device=dev)
+        # steer-rate model (SADBM_CBF_2DS): the filter integrates its own slip angle; the cones follow it
+        self.slip = torch.zeros((A, 2), dtype=ty, device=dev) if cbf.params.dynamics == _lib.DYN_SADBM else None
 
     def rollout(self, ticks, motion="static", trace=False, seek_gain=0.2, seek_v_min=3.0):
         """`ticks` ticks in ONE launch (sccbf_rollout_*): state, target_idx and pid_state advance in
@@ -168,6 +173,10 @@ class ClosedLoop:
     def tick(self):
         if self.nominal is not None:
             self.nominal.control(self.state, self.traj, self.target_idx, self.pid_state, u_ref=self.u_ref)
-        self.cbf.solve(self.state, self.u_ref, self.obs, self.obs_type, u_out=self.u, status=self.status)
+        if self.slip is not None:
+            self.cbf.solve(self.state, self.u_ref, self.obs, self.obs_type, u_out=self.u, status=self.status,
+                           slip=self.slip, dt=self.dt, cone_beta_state=True)
+        else:
+            self.cbf.solve(self.state, self.u_ref, self.obs, self.obs_type, u_out=self.u, status=self.status)
         vehicle_step(self.state, self.u, lr=self.cbf.params.lr, lf=self.cbf.params.lf,
                      max_steer=self.max_steer, dt=self.dt, beta_out=self.beta)
