@@ -390,7 +390,8 @@ int lane_fit_impl(int64_t A, int32_t K, int32_t degree, const T* px, const T* py
     FArgs<T> k;
     k.A = A; k.K = K; k.degree = degree; k.m = m; k.M = M; k.flags = flags;
     k.px = px; k.py = py; k.sigma = sigma; k.buffer = (T)buffer; k.obs = obs;
-    const long long blocks = (A + kBlock - 1) / kBlock;
+    const long long per_block = kBlock / FitLanes<T>::value;
+    const long long blocks = (A + per_block - 1) / per_block;
     hipLaunchKernelGGL((k_lane_fit<T>), dim3((unsigned)blocks), dim3(kBlock), 0,
                        reinterpret_cast<hipStream_t>(stream), k);
     return hipGetLastError() == hipSuccess ? SCCBF_OK : SCCBF_ERR_LAUNCH;
