@@ -14,7 +14,11 @@
  * lane rows have no reference-held numbers: for those this oracle is checked
  * against a second, independent algorithm in this file, against SciPy's SLSQP
  * and by KKT residuals ("parity unpinned" against cvxopt itself, which is not
- * installed here).
+ * installed here).  The rows of the unicycle-input and steer-rate models
+ * (DUM_CBF_2DS, SADBM_CBF_2DS) are restated from the reference's formulas and
+ * checked against the matrix products it writes down; the reference holds no
+ * numbers for them (DUM does not run as shipped, SADBM is commented out in its
+ * drivers): parity unpinned.
  *
  * Every function cites the reference lines (relative to /root/reference) whose
  * arithmetic it restates.
