@@ -65,8 +65,9 @@ template <typename T> struct FArgs {
 };
 
 // Lanes per agent in the lane fit (lane g takes the points g, g + G, ...): four for fp32 data, one
-// for fp64 data, whose rows a group of four would read in 128-byte pieces (measured: 55 against
-// 69 us in fp32 and 94 against 72 us in fp64 for 65536 agents x 32 points, cubic).
+// for fp64 data, whose rows a group of four would read in 128-byte pieces (measured with every
+// pass reading the points again: 55 against 69 us in fp32 and 94 against 72 us in fp64 for
+// 65536 agents x 32 points, cubic).
 template <typename T> struct FitLanes { static constexpr int value = sizeof(T) == 4 ? 4 : 1; };
 
 // This lane's usable points of agent a, 32 / G ... 8 loads in flight at a time.
@@ -147,6 +148,31 @@ __global__ __launch_bounds__(kBlock) void k_lane_fit(const FArgs<T> p)
     double hs = 0.5 * (xmax - xmin);
     if (!(hs > 0.0)) hs = 1.0;
     const double ihs = 1.0 / hs;
+    // Up to kHeld points per lane stay in registers as (t, y, w) for the passes below (a point that
+    // does not count has w = 0); longer lists are read again on every pass.
+    constexpr int kHeld = 8;
+    const bool held = p.K <= kHeld * kFitLanes;  // the same for every thread
+    double ht[kHeld], hy[kHeld], hw[kHeld];
+    if (held) {
+#pragma unroll
+        for (int i = 0; i < kHeld; ++i) {
+            const int k = g + i * kFitLanes, kk = min(k, p.K - 1);
+            const double x = (double)p.px[(long long)kk * p.A + a], y = (double)p.py[(long long)kk * p.A + a];
+            const double sg = p.sigma ? (double)p.sigma[(long long)kk * p.A + a] : 10.0;
+            const bool use = k < p.K && sg > 0.0 && isfinite(sg) && isfinite(x) && isfinite(y);
+            ht[i] = use ? (x - xc) * ihs : 0.0;
+            hy[i] = use ? y : 0.0;
+            hw[i] = use ? 1.0 / (sg * sg) : 0.0;
+        }
+    }
+    auto each = [&](auto&& fn) {  // fn(t, y, w) for this lane's points
+        if (held) {
+#pragma unroll
+            for (int i = 0; i < kHeld; ++i) fn(ht[i], hy[i], hw[i]);
+        } else {
+            for_points_<kFitLanes>(p, a, g, [&](double x, double y, double sg) { fn((x - xc) * ihs, y, 1.0 / (sg * sg)); });
+        }
+    };
     // P_0 = 1, P_{j+1} = (t - al_j) P_j - be_j P_{j-1};  fit = sum_j cf_j P_j
     double al[4] = {0, 0, 0, 0}, be[4] = {0, 0, 0, 0}, cf[4] = {0, 0, 0, 0}, nrm[4] = {1, 1, 1, 1};
     double prev_norm = 1.0;
@@ -154,8 +180,7 @@ __global__ __launch_bounds__(kBlock) void k_lane_fit(const FArgs<T> p)
     for (int j = 0; j < 4; ++j) {
         if (j >= n) break;
         double nn = 0.0, ta = 0.0, mm = 0.0;
-        for_points_<kFitLanes>(p, a, g, [&](double x, double, double sg) {
-            const double w = 1.0 / (sg * sg), t = (x - xc) * ihs;
+        each([&](double t, double, double w) {
             double pm = 0.0, pj = 1.0, qm = 0.0, qj = 1.0;  // P_{i-1}, P_i and bounds of the terms they sum
             for (int i = 0; i < j; ++i) {
                 const double pn = (t - al[i]) * pj - be[i] * pm;
@@ -177,8 +202,7 @@ __global__ __launch_bounds__(kBlock) void k_lane_fit(const FArgs<T> p)
     // cf_j = <y, P_j> / <P_j, P_j>, then once more with the residuals y - fit in place of y
     for (int pass = 0; pass < 2; ++pass) {
         double gs[4] = {0, 0, 0, 0};
-        for_points_<kFitLanes>(p, a, g, [&](double x, double y, double sg) {
-            const double w = 1.0 / (sg * sg), t = (x - xc) * ihs;
+        each([&](double t, double y, double w) {
             double P[4];
             P[0] = 1.0;
             P[1] = t - al[0];
