@@ -66,9 +66,16 @@ def main():
     ap.add_argument("--cases", type=int, default=200)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--only", type=int, default=-1)
+    ap.add_argument("--dtype", default="f64", choices=["f64", "f32"],
+                    help="f32: the two fp32 paths round differently tick by tick, so an agent is judged while an fp32 "
+                         "ulp on the data stays below 3e-6, to 5e-2 (a detector of gross errors: a wrong slot, kind or "
+                         "tick order moves the inputs by O(1))")
     args = ap.parse_args()
     rng = np.random.default_rng(args.seed)
     orc.build()
+    dt_t = torch.float64 if args.dtype == "f64" else torch.float32
+    dt_n = np.float64 if args.dtype == "f64" else np.float32
+    calm_lim, miss_lim = (1e-12, 1e-6) if args.dtype == "f64" else (3e-6, 5e-2)
     misses, agents, diverged = 0, 0, 0
     for case in range(args.cases):
         M = int(rng.choice([1, 2, 3, 4, 5, 8, 12, 16, 17, 31, 32, 33, 48, 64]))
@@ -100,10 +107,11 @@ def main():
             case, A, M, T, N, motion, per_agent, tiled, pid, wps, dt)
 
         def make(state=state, obs=obs):
-            tobs = torch.from_numpy(obs).to(DEV)
+            tobs = torch.from_numpy(obs).to(DEV).to(dt_t)
             nom = BatchedNominal(axle=2.9, k=0.5, ks=0.01, kp=1.0, ki=0.2, kd=0.02, dt=dt, waypoint_speed=wps) if N else None
             return ClosedLoop(BatchedCBF(alpha=1.0, R=np.diag([0.5, 0.5])), nom,
-                              torch.from_numpy(traj).to(DEV) if N else None, torch.from_numpy(state.copy()).to(DEV),
+                              torch.from_numpy(traj).to(DEV).to(dt_t) if N else None,
+                              torch.from_numpy(state.copy()).to(DEV).to(dt_t),
                               planes_to_tiled(tobs) if tiled else tobs, torch.from_numpy(ty).to(DEV),
                               dt=dt, use_pid_state=pid and N > 0)
         def tick_by_tick(la, obs=obs):
@@ -114,20 +122,21 @@ def main():
                     la.nominal.control(la.state, la.traj, la.target_idx, la.pid_state, u_ref=la.u_ref)
                 u, st = la.cbf.solve(la.state, la.u_ref, la.obs, la.obs_type, u_out=la.u, status=la.status)
                 vehicle_step(la.state, la.u, lr=1.45, lf=1.45, max_steer=la.max_steer, dt=dt, beta_out=la.beta)
-                tr.append(torch.cat([u, la.beta[:, None], st.double()[:, None]], dim=1).clone())
+                tr.append(torch.cat([u, la.beta[:, None], st.to(dt_t)[:, None]], dim=1).double())
                 if motion == "constant_velocity":
                     advance(host, ty, dt)
                 elif motion == "seeker":
-                    seek(host, ty, la.state[:, 0:2].cpu().numpy(), dt, gain, vmin)
+                    seek(host, ty, la.state[:, 0:2].double().cpu().numpy(), dt, gain, vmin)
                 if motion != "static":
-                    tobs = torch.from_numpy(host).to(DEV)
+                    tobs = torch.from_numpy(host).to(DEV).to(dt_t)
                     la.obs = planes_to_tiled(tobs) if tiled else tobs
             return torch.stack(tr), host
         la = make()
         tr, host = tick_by_tick(la)
         # how sensitive each closed loop is: the same ticks from data one fp64 ulp away (two trials)
         prng = np.random.default_rng([args.seed, case])
-        ulp = lambda v: np.nextafter(v, np.where(prng.integers(0, 2, v.shape) == 1, np.inf, -np.inf))   # noqa: E731
+        ulp = lambda v: np.nextafter(v.astype(dt_n), np.where(prng.integers(0, 2, v.shape) == 1, np.inf, -np.inf)   # noqa: E731
+                                     .astype(dt_n)).astype(np.float64)
         probes = []
         for _ in range(2):
             o2 = ulp(obs)
@@ -136,6 +145,7 @@ def main():
         out = lb.rollout(T, motion=motion, trace=True, seek_gain=gain, seek_v_min=vmin)
         torch.cuda.synchronize()
         agents += A
+        out["trace"] = out["trace"].double()
         same = (out["trace"][:, :, 3] == tr[:, :, 3]).all(dim=0)
         # an agent driven to inputs of 1e4 and more (a vertex on nearly parallel rows) amplifies the last
         # bits within a few ticks: its history is compared up to the tick before it first gets there
@@ -145,14 +155,17 @@ def main():
         # steering that flips sign from tick to tick: such loops multiply a difference by 50 and more per tick)
         for tr2 in probes:
             e = ((tr2[:, :, :3] - tr[:, :, :3]).abs().amax(dim=2) / (1 + tr[:, :, :2].abs().amax(dim=2)))
-            calm &= (torch.cummax(e, dim=0).values < 1e-12) & (tr2[:, :, 3] == tr[:, :, 3]).cumprod(dim=0).bool()
+            calm &= (torch.cummax(e, dim=0).values < calm_lim) & (tr2[:, :, 3] == tr[:, :, 3]).cumprod(dim=0).bool()
         diverged += int((~calm[-1]).sum())
         dmax = float(torch.where(calm, d, torch.zeros_like(d)).max())
         smis = int(((out["trace"][:, :, 3] != tr[:, :, 3]) & calm).sum())
         ok_state = calm[-1]
-        ds = float(((lb.state - la.state).abs().amax(dim=1) / (1 + la.state.abs().amax(dim=1)))[ok_state].max()) if ok_state.any() else 0.0
+        ds = float(((lb.state - la.state).double().abs().amax(dim=1) / (1 + la.state.double().abs().amax(dim=1)))[ok_state].max()) if ok_state.any() else 0.0
         di = int((lb.target_idx - la.target_idx)[ok_state].abs().max()) if N and ok_state.any() else 0
-        if dmax > 1e-6 or smis > 0 or ds > 1e-6 or di > 0:
+        if args.dtype == "f32":     # near-ties between way-points 0.1 m apart, verdicts on the edge of feasibility
+            di = 0 if di <= 2 else di
+            smis = 0 if smis <= max(1, A * T // 2000) else smis
+        if dmax > miss_lim or smis > 0 or ds > miss_lim or di > 0:
             misses += 1
             print("MISS %s: trace %.3g, status differs on %d agent-ticks, state %.3g, target index %d" % (tag, dmax, smis, ds, di),
                   flush=True)
@@ -193,7 +206,8 @@ def main():
                 print("    ", host[m, :, a_, :].reshape(-1), " dist to ego %.4g" % np.hypot(*(host[m, 0, a_, :2] - la.state[a_, :2].cpu().numpy())))
         if case % 50 == 49:
             print("... %d cases done, %d misses" % (case + 1, misses), flush=True)
-    print("cases %d, agents %d (%d left the range where an ulp on the data stays below 1e-12), misses %d" % (args.cases, agents, diverged, misses))
+    print("cases %d %s, agents %d (%d left the range where an ulp on the data stays below %g), misses %d"
+          % (args.cases, args.dtype, agents, diverged, calm_lim, misses))
     sys.exit(1 if misses else 0)
 
 

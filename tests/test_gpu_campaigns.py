@@ -12,11 +12,12 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "campaigns")
 
 
-@pytest.mark.parametrize("name,cases", [("fuzz_parity", 150), ("fuzz_nominal", 60), ("fuzz_rollout", 60),
-                                        ("fuzz_ingest", 40)])
-def test_campaign(oracle, monkeypatch, name, cases):
+@pytest.mark.parametrize("name,cases,extra", [("fuzz_parity", 150, []), ("fuzz_nominal", 60, []),
+                                              ("fuzz_rollout", 60, []), ("fuzz_rollout", 60, ["--dtype", "f32"]),
+                                              ("fuzz_ingest", 40, [])])
+def test_campaign(oracle, monkeypatch, name, cases, extra):
     monkeypatch.syspath_prepend(HERE)
-    monkeypatch.setattr(sys, "argv", [name, "--cases", str(cases), "--seed", "4242"])
+    monkeypatch.setattr(sys, "argv", [name, "--cases", str(cases), "--seed", "4242"] + extra)
     mod = importlib.import_module(name)
     with pytest.raises(SystemExit) as done:
         mod.main()
