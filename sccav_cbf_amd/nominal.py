@@ -125,12 +125,14 @@ class ClosedLoop:
         # steer-rate model (SADBM_CBF_2DS): the filter integrates its own slip angle; the cones follow it
         self.slip = torch.zeros((A, 2), dtype=ty, device=dev) if cbf.params.dynamics == _lib.DYN_SADBM else None
 
-    def rollout(self, ticks, motion="static", trace=False, seek_gain=0.2, seek_v_min=3.0):
+    def rollout(self, ticks, motion="static", trace=False, seek_gain=0.2, seek_v_min=3.0, out=None):
         """`ticks` ticks in ONE launch (sccbf_rollout_*): state, target_idx and pid_state advance in
         place; obstacles may move inside the launch, with constant velocity or as seekers of
         radial_dynamic_obstacles.py:193-239 (`obs` itself is not written).
         Returns a dict: h_min (A,), n_active (A,), n_infeasible (A,) and, if asked for,
-        trace (ticks, A, 4) = a*, delta*, beta, status per tick."""
+        trace (ticks, A, 4) = a*, delta*, beta, status per tick.  Pass the dict of an earlier call
+        as `out` to write into its tensors again: the call then allocates nothing and may be
+        captured in a hipGraph."""
         A, dev, ty = self.state.shape[0], self.state.device, self.state.dtype
         obs = self.obs
         flags = self.cbf.params.flags & ~(_lib.FLAG_OBS_SHARED | _lib.FLAG_OBS_TILED | _lib.FLAG_TYPE_PER_AGENT)
@@ -154,11 +156,18 @@ class ClosedLoop:
                      "seeker": _lib.MOTION_SEEKER}[motion]
         rp.seek_gain, rp.seek_v_min = float(seek_gain), float(seek_v_min)
         nominal_params = self.nominal.params if self.nominal is not None else _lib.NominalParams()
-        out = dict(h_min=torch.empty((A,), dtype=ty, device=dev),
-                   n_active=torch.empty((A,), dtype=torch.int32, device=dev),
-                   n_infeasible=torch.empty((A,), dtype=torch.int32, device=dev))
-        if trace:
-            out["trace"] = torch.empty((int(ticks), A, 4), dtype=ty, device=dev)
+        if out is None:
+            out = dict(h_min=torch.empty((A,), dtype=ty, device=dev),
+                       n_active=torch.empty((A,), dtype=torch.int32, device=dev),
+                       n_infeasible=torch.empty((A,), dtype=torch.int32, device=dev))
+            if trace:
+                out["trace"] = torch.empty((int(ticks), A, 4), dtype=ty, device=dev)
+        else:
+            _check("out['h_min']", out["h_min"], (A,), ty, dev)
+            _check("out['n_active']", out["n_active"], (A,), torch.int32, dev)
+            _check("out['n_infeasible']", out["n_infeasible"], (A,), torch.int32, dev)
+            if "trace" in out:
+                _check("out['trace']", out["trace"], (int(ticks), A, 4), ty, dev)
         self.cbf.params.flags = flags
         fn = lib.sccbf_rollout_f32 if ty == torch.float32 else lib.sccbf_rollout_f64
         with torch.cuda.device(dev):

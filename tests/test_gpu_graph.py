@@ -98,3 +98,41 @@ def test_closed_loop_ticks_replay_equal_eager():
             torch.cuda.synchronize()
             for name in ("state", "u", "u_ref", "status", "beta", "target_idx", "pid_state"):
                 assert torch.equal(getattr(loop, name), getattr(ref, name)), (replay, name)
+
+
+def test_rollout_replays_equal_eager():
+    g_ = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sce_course.npz"))
+    traj = torch.from_numpy(np.stack([g_["cx"], g_["cy"], g_["cyaw"], np.full_like(g_["cx"], 8.0)], axis=1)).float().to(DEV)
+    A, T = 1000, 12
+    w = scenarios.config4(A=A, seed=8, nominal="uniform")
+    rng = np.random.default_rng(9)
+    at = rng.integers(0, traj.shape[0] - 300, A)
+    xy = np.stack([g_["cx"][at] + rng.normal(0, 2, A), g_["cy"][at] + rng.normal(0, 2, A)], axis=1)
+    w["obs"][:, 0, :, 0:2] += (xy - w["state"][:, 0:2])[None, :, :]
+    w["state"][:, 0:2] = xy
+    w["state"][:, 2] = g_["cyaw"][at]
+    state0 = torch.from_numpy(w["state"]).float().to(DEV)
+    loop = ClosedLoop(BatchedCBF(alpha=1.0, R=np.diag([0.5, 0.5])), BatchedNominal(axle=2.9, k=0.5, ks=0.01), traj,
+                      state0.clone(), torch.from_numpy(w["obs"]).float().to(DEV), torch.from_numpy(w["obs_type"]).to(DEV))
+    ref = loop.rollout(T, motion="constant_velocity", trace=True)
+    torch.cuda.synchronize()
+    ref = {k: v.clone() for k, v in ref.items()}
+    ref_state = loop.state.clone()
+    out = {k: torch.empty_like(v) for k, v in ref.items()}
+    stream = torch.cuda.Stream(DEV)
+    with torch.cuda.stream(stream):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=stream):
+            loop.state.copy_(state0)
+            loop.target_idx.fill_(0)
+            loop.rollout(T, motion="constant_velocity", out=out)
+        for replay in range(3):
+            for v in out.values():
+                v.fill_(0)
+            loop.state.fill_(0)
+            torch.cuda.synchronize()
+            g.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(loop.state, ref_state), replay
+            for k in ref:
+                assert torch.equal(out[k], ref[k]), (replay, k)
