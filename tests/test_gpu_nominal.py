@@ -349,3 +349,31 @@ def test_radial_seeker_scenario_by_one_rollout_launch(oracle):
     assert np.abs(got[:, :, :3] - tr[:, :, :3]).max() <= 1e-7 * (1 + np.abs(tr[:, :, :3]).max())
     assert np.abs(loop.state.cpu().numpy() - s).max() <= 1e-7 * (1 + np.abs(s).max())
     assert np.abs(out["h_min"].cpu().numpy() - hmin).max() <= 1e-7 * (1 + np.abs(hmin).max())
+
+
+def test_c1_with_the_true_ellipse_row_by_one_rollout_launch():
+    """The same scenario constrained by the ellipse itself (Ellipse2D a = 20, b = 10 at the obstacle's
+    centre; the inline CBF_A of stanley_controller_ellipse.py:277-318) in one launch, against the
+    oracle's replay of that loop tick by tick; the ego never enters the ellipse."""
+    from sccav_cbf_amd.batched import BatchedCBF, ellipse_slots, pack_obs
+    from sccav_cbf_amd.nominal import BatchedNominal, ClosedLoop
+    t_ref, beta_ref, log = replay.replay_stanley_cone(row_kind="ellipse")
+    traj = _course()
+    k = replay.scenario_constants(traj[:, 0], traj[:, 1])
+    A = 3
+    state = torch.tensor([[0.0, 5.0, np.radians(20.0), 10.0]] * A, dtype=torch.float64, device=DEV)
+    one = torch.ones((A,), dtype=torch.float64, device=DEV)
+    zero = one * 0.0
+    obs = pack_obs(ellipse_slots(one * k["o_cx"], one * k["o_cy"], one * k["a"], one * k["b"], zero, zero, zero)[None])
+    ty = torch.tensor([_lib.OBS_ELLIPSE], dtype=torch.uint8, device=DEV)
+    loop = ClosedLoop(BatchedCBF(alpha=1.0, lr=replay.LR, lf=replay.LF, R=np.diag([0.5, 0.5])),
+                      BatchedNominal(axle=replay.WHEELBASE, k=replay.K_STANLEY, ks=0.0, kp=replay.KP,
+                                     target_speed=k["target_speed"]),
+                      torch.from_numpy(traj).to(DEV), state, obs, ty, max_steer=replay.MAX_STEER, dt=replay.DT)
+    T = len(t_ref) - 1
+    out = loop.rollout(T, trace=True)
+    torch.cuda.synchronize()
+    tr = out["trace"][:, 0, :].cpu().numpy()
+    assert np.abs(np.degrees(tr[:, 2]) - beta_ref[1:]).max() <= 1e-6
+    assert np.abs(tr[:, 0] - np.array([l[3] for l in log])).max() <= 1e-7
+    assert (tr[:, 3] == 0).all() and float(out["h_min"][0]) > -1e-6 and int(out["n_active"][0]) > 10
