@@ -641,7 +641,8 @@ double orc_stanley(const double s[4], int n, const double* cx, const double* cy,
     double err = (fx - cx[best]) * ex + (fy - cy[best]) * ey;
     int idx = best;
     if (last_idx >= idx) idx = last_idx;
-    double theta_e = orc_normalize_angle(cyaw[idx] - s[2]);
+    /* a caller's index beyond the course (the reference would raise IndexError) reads the last way-point */
+    double theta_e = orc_normalize_angle(cyaw[idx < n ? idx : n - 1] - s[2]);
     double theta_d = atan2(k * err, s[3] + ks);
     *idx_out = idx;
     return theta_e + theta_d;

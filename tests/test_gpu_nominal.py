@@ -377,3 +377,19 @@ def test_c1_with_the_true_ellipse_row_by_one_rollout_launch():
     assert np.abs(np.degrees(tr[:, 2]) - beta_ref[1:]).max() <= 1e-6
     assert np.abs(tr[:, 0] - np.array([l[3] for l in log])).max() <= 1e-7
     assert (tr[:, 3] == 0).all() and float(out["h_min"][0]) > -1e-6 and int(out["n_active"][0]) > 10
+
+
+def test_target_index_beyond_the_course_reads_the_last_way_point(oracle):
+    """A caller's stale index (a longer course before) must not read past the course."""
+    traj = _course()[:200]
+    A = 300
+    state, _ = _agents(A, 21, traj)
+    tgt = np.random.default_rng(1).integers(0, 5000, A).astype(np.int32)
+    tgt_o = tgt.copy()
+    uo = oracle.nominal_batch(state, traj, tgt_o, axle=2.9, k=0.5, ks=0.01)
+    from sccav_cbf_amd.nominal import BatchedNominal
+    tg = torch.from_numpy(tgt.copy()).to(DEV)
+    ug = BatchedNominal(axle=2.9, k=0.5, ks=0.01).control(torch.from_numpy(state).to(DEV), torch.from_numpy(traj).to(DEV), tg)
+    torch.cuda.synchronize()
+    assert np.array_equal(tg.cpu().numpy(), tgt_o)
+    assert np.abs(ug.cpu().numpy() - uo).max() <= 1e-9
