@@ -393,3 +393,32 @@ def test_target_index_beyond_the_course_reads_the_last_way_point(oracle):
     torch.cuda.synchronize()
     assert np.array_equal(tg.cpu().numpy(), tgt_o)
     assert np.abs(ug.cpu().numpy() - uo).max() <= 1e-9
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
+def test_nonfinite_and_diverged_states_do_not_disturb_their_neighbours(dtype):
+    """NaN, infinite and absurdly large states in a batch: the kernels return, the other agents'
+    results are what they are without those agents, and the rollout flags the bad ones."""
+    from sccav_cbf_amd.nominal import BatchedNominal
+    A, M, T = 300, 8, 6
+    make = _rollout_case(A, M, 91, dtype, True)
+    clean, _, _ = make()
+    out_clean = clean.rollout(T, trace=True)
+    dirty, _, _ = make()
+    bad = torch.tensor([3, 64, 65, 130, 299], device=DEV)
+    vals = torch.tensor([[float("nan"), 0, 0, 5], [0, float("inf"), 0, 5], [1e30, 1e30, 1e17, 5],
+                         [0, 0, float("-inf"), 5], [0, 0, 0, float("nan")]], dtype=dtype, device=DEV)
+    dirty.state[bad] = vals
+    state_in = dirty.state.clone()
+    tgt = torch.zeros((A,), dtype=torch.int32, device=DEV)
+    u = BatchedNominal(axle=2.9).control(state_in, dirty.traj, tgt)
+    torch.cuda.synchronize()
+    good = torch.ones(A, dtype=torch.bool, device=DEV)
+    good[bad] = False
+    assert torch.isfinite(u[good]).all() and (tgt >= 0).all() and (tgt < dirty.traj.shape[0]).all()
+    out = dirty.rollout(T, trace=True)
+    torch.cuda.synchronize()
+    assert torch.equal(out["trace"][:, good], out_clean["trace"][:, good])
+    assert torch.equal(dirty.state[good], clean.state[good])
+    st0 = out["trace"][0, bad, 3]
+    assert (st0[[0, 1, 3, 4]] == 2).all()          # non-finite state: flagged on the first tick
