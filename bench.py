@@ -9,6 +9,8 @@ A step = one control tick (barrier rows + 2-input QP) for one batch of 65536 age
 HBM before the timed region; the steps walk a ring of distinct batches larger than the
 256 MiB Infinity Cache so every step streams its inputs from HBM.  Ranks hold independent
 batches (weak scaling, no data-path collective).  Rank 0 prints ONE JSON line.
+Order: untimed clock ramp (--ramp-ms of work, an idle GPU is slow for its first milliseconds),
+W untimed warm-up steps, barrier, exactly K timed steps, barrier.
 """
 import argparse
 import json
@@ -154,6 +156,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
     ap.add_argument("--planes", action="store_true", help="obstacles as (M,2,A,4) planes instead of 64-agent tiles")
     ap.add_argument("--no-large", action="store_true", help="skip the extra 1M-agent measurement (N=1 only)")
+    ap.add_argument("--ramp-ms", type=float, default=60.0,
+                    help="untimed work ahead of the warm-up steps that lets an idle GPU reach its clocks")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -204,6 +208,14 @@ def main():
             for i in range(done, k):
                 step(i)
 
+        # An idle GPU needs some ten milliseconds of work to reach its clocks, more than a short
+        # warm-up gives it: untimed walks over the ring first, then the W warm-up steps.
+        ramp_steps = 0
+        t_ramp = time.perf_counter()
+        while (time.perf_counter() - t_ramp) * 1e3 < args.ramp_ms:
+            run(10 * RING)
+            torch.cuda.synchronize()
+            ramp_steps += 10 * RING
         run(args.warmup)
         barrier()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -268,7 +280,8 @@ def main():
                                    "DBM filter, alpha=1, R=diag(.5,.5), ring of %d distinct batches" % (A, RING),
                        "agents_per_gpu": A, "rows": M, "lanes_per_qp": args.lanes,
                        "obs_layout": "planes (M,2,A,4)" if args.planes else "tiles (A/64,M,2,64,4)",
-                       "launch": "eager" if graph is None else "hipGraph of %d launches" % RING},
+                       "launch": "eager" if graph is None else "hipGraph of %d launches" % RING,
+                       "clock_ramp_steps_before_warmup": ramp_steps},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "kernel_ms": kern_ms,
