@@ -390,10 +390,27 @@ int lane_fit_impl(int64_t A, int32_t K, int32_t degree, const T* px, const T* py
     FArgs<T> k;
     k.A = A; k.K = K; k.degree = degree; k.m = m; k.M = M; k.flags = flags;
     k.px = px; k.py = py; k.sigma = sigma; k.buffer = (T)buffer; k.obs = obs;
-    const long long per_block = kBlock / FitLanes<T>::value;
-    const long long blocks = (A + per_block - 1) / per_block;
-    hipLaunchKernelGGL((k_lane_fit<T>), dim3((unsigned)blocks), dim3(kBlock), 0,
-                       reinterpret_cast<hipStream_t>(stream), k);
+    // Lanes per agent and points held per lane, by the length of the lists (65536 agents, cubic, us per
+    // launch): up to 8 points one lane holds them all; up to 32 / 64 four lanes hold 8 / 16 each; beyond
+    // that the points are read again on every pass, by four lanes in fp32 and by one in fp64.
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    auto launch = [&](auto lanes, auto heldc) {
+        constexpr int G = decltype(lanes)::value, H = decltype(heldc)::value;
+        const long long per_block = kBlock / G;
+        const dim3 grid((unsigned)((A + per_block - 1) / per_block)), block(kBlock);
+        switch (degree) {
+        case 0: hipLaunchKernelGGL((k_lane_fit<T, 1, G, H>), grid, block, 0, st, k); break;
+        case 1: hipLaunchKernelGGL((k_lane_fit<T, 2, G, H>), grid, block, 0, st, k); break;
+        case 2: hipLaunchKernelGGL((k_lane_fit<T, 3, G, H>), grid, block, 0, st, k); break;
+        default: hipLaunchKernelGGL((k_lane_fit<T, 4, G, H>), grid, block, 0, st, k); break;
+        }
+    };
+    using std::integral_constant;
+    if (K <= 8) launch(integral_constant<int, 1>{}, integral_constant<int, 8>{});
+    else if (K <= 32) launch(integral_constant<int, 4>{}, integral_constant<int, 8>{});
+    else if (K <= 64) launch(integral_constant<int, 4>{}, integral_constant<int, 16>{});
+    else if (sizeof(T) == 4) launch(integral_constant<int, 4>{}, integral_constant<int, 0>{});
+    else launch(integral_constant<int, 1>{}, integral_constant<int, 0>{});
     return hipGetLastError() == hipSuccess ? SCCBF_OK : SCCBF_ERR_LAUNCH;
 }
 

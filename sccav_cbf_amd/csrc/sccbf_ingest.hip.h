@@ -64,12 +64,6 @@ template <typename T> struct FArgs {
     T* obs;
 };
 
-// Lanes per agent in the lane fit (lane g takes the points g, g + G, ...): four for fp32 data, one
-// for fp64 data, whose rows a group of four would read in 128-byte pieces (measured with every
-// pass reading the points again: 55 against 69 us in fp32 and 94 against 72 us in fp64 for
-// 65536 agents x 32 points, cubic).
-template <typename T> struct FitLanes { static constexpr int value = sizeof(T) == 4 ? 4 : 1; };
-
 // This lane's usable points of agent a, 32 / G ... 8 loads in flight at a time.
 template <int kFitLanes, typename T, typename F>
 __device__ inline void for_points_(const FArgs<T>& p, long long a, int g, F&& fn)
@@ -122,23 +116,46 @@ template <int G> __device__ inline double fit_sum_(double v)
 // (fewer distinct abscissae than coefficients: the next orthogonal polynomial vanishes on all of
 // them, up to its own rounding) the coefficients are NaN and the filter reports the agent as
 // non-finite.
-template <typename T>
-__global__ __launch_bounds__(kBlock) void k_lane_fit(const FArgs<T> p)
+// N = degree + 1 coefficients (every loop over them unrolls, nothing is indexed at run time);
+// kFitLanes lanes per agent (lane g takes the points g, g + kFitLanes, ...); kHeld points per lane
+// stay in registers for all passes (the host launches this form for K <= kHeld * kFitLanes), or with
+// kHeld = 0 the lists are read again on every pass.
+template <typename T, int N, int kFitLanes, int kHeld>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kHeld == 16 ? 2 : 3, 8))) void k_lane_fit(const FArgs<T> p)
 {
     using v4 = typename VT<T>::v4;
-    constexpr int kFitLanes = FitLanes<T>::value;
     static_assert(kFitLanes == 1 || kFitLanes == 4, "none or two shuffle rounds");
+    static_assert(N >= 1 && N <= 4, "constant to cubic");
     const int g = threadIdx.x % kFitLanes;
     const long long a = (long long)blockIdx.x * (kBlock / kFitLanes) + threadIdx.x / kFitLanes;
     if (a >= p.A) return;  // the four lanes of an agent leave together
-    const int n = p.degree + 1;
+    // a held point that does not count has w = 0
+    constexpr bool held = kHeld > 0;
+    constexpr int kSlots = held ? kHeld : 1;
+    double ht[kSlots], hy[kSlots], hw[kSlots];
     double xmin = INFINITY, xmax = -INFINITY;
     int cnt = 0;
-    for_points_<kFitLanes>(p, a, g, [&](double x, double, double) {
-        xmin = fmin(xmin, x);
-        xmax = fmax(xmax, x);
-        ++cnt;
-    });
+    if constexpr (held) {
+#pragma unroll
+        for (int i = 0; i < kSlots; ++i) {
+            const int k = g + i * kFitLanes, kk = min(k, p.K - 1);
+            const double x = (double)p.px[(long long)kk * p.A + a], y = (double)p.py[(long long)kk * p.A + a];
+            const double sg = p.sigma ? (double)p.sigma[(long long)kk * p.A + a] : 10.0;
+            const bool use = k < p.K && sg > 0.0 && isfinite(sg) && isfinite(x) && isfinite(y);
+            ht[i] = x;
+            hy[i] = use ? y : 0.0;
+            hw[i] = use ? 1.0 / (sg * sg) : 0.0;
+            xmin = use ? fmin(xmin, x) : xmin;
+            xmax = use ? fmax(xmax, x) : xmax;
+            cnt += use;
+        }
+    } else {
+        for_points_<kFitLanes>(p, a, g, [&](double x, double, double) {
+            xmin = fmin(xmin, x);
+            xmax = fmax(xmax, x);
+            ++cnt;
+        });
+    }
     if (kFitLanes == 4) {
         xmin = fmin(xmin, fit_shfl_(xmin, 1)); xmin = fmin(xmin, fit_shfl_(xmin, 2));
         xmax = fmax(xmax, fit_shfl_(xmax, 1)); xmax = fmax(xmax, fit_shfl_(xmax, 2));
@@ -148,40 +165,28 @@ __global__ __launch_bounds__(kBlock) void k_lane_fit(const FArgs<T> p)
     double hs = 0.5 * (xmax - xmin);
     if (!(hs > 0.0)) hs = 1.0;
     const double ihs = 1.0 / hs;
-    // Up to kHeld points per lane stay in registers as (t, y, w) for the passes below (a point that
-    // does not count has w = 0); longer lists are read again on every pass.
-    constexpr int kHeld = 8;
-    const bool held = p.K <= kHeld * kFitLanes;  // the same for every thread
-    double ht[kHeld], hy[kHeld], hw[kHeld];
-    if (held) {
+    if constexpr (held) {
 #pragma unroll
-        for (int i = 0; i < kHeld; ++i) {
-            const int k = g + i * kFitLanes, kk = min(k, p.K - 1);
-            const double x = (double)p.px[(long long)kk * p.A + a], y = (double)p.py[(long long)kk * p.A + a];
-            const double sg = p.sigma ? (double)p.sigma[(long long)kk * p.A + a] : 10.0;
-            const bool use = k < p.K && sg > 0.0 && isfinite(sg) && isfinite(x) && isfinite(y);
-            ht[i] = use ? (x - xc) * ihs : 0.0;
-            hy[i] = use ? y : 0.0;
-            hw[i] = use ? 1.0 / (sg * sg) : 0.0;
-        }
+        for (int i = 0; i < kSlots; ++i) ht[i] = hw[i] != 0.0 ? (ht[i] - xc) * ihs : 0.0;
     }
     auto each = [&](auto&& fn) {  // fn(t, y, w) for this lane's points
-        if (held) {
+        if constexpr (held) {
 #pragma unroll
-            for (int i = 0; i < kHeld; ++i) fn(ht[i], hy[i], hw[i]);
+            for (int i = 0; i < kSlots; ++i) fn(ht[i], hy[i], hw[i]);
         } else {
             for_points_<kFitLanes>(p, a, g, [&](double x, double y, double sg) { fn((x - xc) * ihs, y, 1.0 / (sg * sg)); });
         }
     };
     // P_0 = 1, P_{j+1} = (t - al_j) P_j - be_j P_{j-1};  fit = sum_j cf_j P_j
-    double al[4] = {0, 0, 0, 0}, be[4] = {0, 0, 0, 0}, cf[4] = {0, 0, 0, 0}, nrm[4] = {1, 1, 1, 1};
+    double al[N], be[N], cf[N], nrm[N];
     double prev_norm = 1.0;
-    bool ok = cnt >= n;
-    for (int j = 0; j < 4; ++j) {
-        if (j >= n) break;
+    bool ok = cnt >= N;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
         double nn = 0.0, ta = 0.0, mm = 0.0;
         each([&](double t, double, double w) {
             double pm = 0.0, pj = 1.0, qm = 0.0, qj = 1.0;  // P_{i-1}, P_i and bounds of the terms they sum
+#pragma unroll
             for (int i = 0; i < j; ++i) {
                 const double pn = (t - al[i]) * pj - be[i] * pm;
                 const double qn = (fabs(t) + fabs(al[i])) * qj + be[i] * qm;
@@ -197,45 +202,58 @@ __global__ __launch_bounds__(kBlock) void k_lane_fit(const FArgs<T> p)
         al[j] = ta / nn;
         be[j] = j ? nn / prev_norm : 0.0;
         nrm[j] = nn;
+        cf[j] = 0.0;
         prev_norm = nn;
     }
     // cf_j = <y, P_j> / <P_j, P_j>, then once more with the residuals y - fit in place of y
+#pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
-        double gs[4] = {0, 0, 0, 0};
+        double gs[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) gs[j] = 0.0;
         each([&](double t, double y, double w) {
-            double P[4];
+            double P[N];
             P[0] = 1.0;
-            P[1] = t - al[0];
-            P[2] = (t - al[1]) * P[1] - be[1] * P[0];
-            P[3] = (t - al[2]) * P[2] - be[2] * P[1];
+#pragma unroll
+            for (int j = 1; j < N; ++j) P[j] = (t - al[j - 1]) * P[j - 1] - (j > 1 ? be[j - 1] * P[j > 1 ? j - 2 : 0] : 0.0);
             double r = y;
-            for (int j = 0; j < 4; ++j) r -= j < n ? cf[j] * P[j] : 0.0;
-            for (int j = 0; j < 4; ++j) gs[j] += w * r * P[j];
+            if (pass) {
+#pragma unroll
+                for (int j = 0; j < N; ++j) r -= cf[j] * P[j];
+            }
+            const double wr = w * r;
+#pragma unroll
+            for (int j = 0; j < N; ++j) gs[j] += wr * P[j];
         });
-        for (int j = 0; j < 4; ++j) cf[j] += j < n ? fit_sum_<kFitLanes>(gs[j]) / nrm[j] : 0.0;
+#pragma unroll
+        for (int j = 0; j < N; ++j) cf[j] += fit_sum_<kFitLanes>(gs[j]) / nrm[j];
     }
     // coefficients of the powers of t, then of x:  p(x) = sum_j d_j ((x - xc) / hs)^j
-    double Pm[4] = {0, 0, 0, 0}, Pj[4] = {1, 0, 0, 0}, d[4] = {0, 0, 0, 0};
-    for (int j = 0; j < 4; ++j) {
-        if (j >= n) break;
-        double Pn[4];
-        for (int k = 0; k < 4; ++k) {
+    double Pm[N], Pj[N], d[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) { Pm[k] = 0.0; Pj[k] = k ? 0.0 : 1.0; d[k] = 0.0; }
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        double Pn[N];
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
             d[k] += cf[j] * Pj[k];
-            Pn[k] = (k ? Pj[k - 1] : 0.0) - al[j] * Pj[k] - be[j] * Pm[k];
+            Pn[k] = (k ? Pj[k ? k - 1 : 0] : 0.0) - al[j] * Pj[k] - be[j] * Pm[k];
         }
-        for (int k = 0; k < 4; ++k) { Pm[k] = Pj[k]; Pj[k] = Pn[k]; }
+#pragma unroll
+        for (int k = 0; k < N; ++k) { Pm[k] = Pj[k]; Pj[k] = Pn[k]; }
     }
-    double e[4], c[4] = {0, 0, 0, 0};
+    double c[4] = {0, 0, 0, 0};
+    constexpr double binom[4][4] = {{1, 0, 0, 0}, {1, 1, 0, 0}, {1, 2, 1, 0}, {1, 3, 3, 1}};
     double sc = 1.0;
-    for (int j = 0; j < 4; ++j) {
-        e[j] = d[j] * sc;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        const double e = d[j] * sc;
         sc *= ihs;
-    }
-    const double binom[4][4] = {{1, 0, 0, 0}, {1, 1, 0, 0}, {1, 2, 1, 0}, {1, 3, 3, 1}};
-    for (int j = 0; j < 4; ++j) {
         double pw = 1.0;  // (-xc)^(j - k), k from j down to 0
+#pragma unroll
         for (int k = j; k >= 0; --k) {
-            c[k] += e[j] * binom[j][k] * pw;
+            c[k] += e * binom[j][k] * pw;
             pw *= -xc;
         }
     }

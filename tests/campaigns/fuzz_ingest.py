@@ -30,7 +30,7 @@ def main():
     misses, fits, nans = 0, 0, 0
     for case in range(args.cases):
         A = int(rng.integers(1, 300))
-        K = int(rng.integers(1, 48))
+        K = int(rng.integers(1, 48)) if rng.random() < 0.8 else int(rng.integers(48, 140))
         deg = int(rng.integers(0, 4))
         M = int(rng.integers(1, 6))
         slot = int(rng.integers(0, M))

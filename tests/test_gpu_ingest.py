@@ -45,10 +45,12 @@ def test_ingest_bbox_matches_oracle(oracle, dtype, per_agent, A):
 
 
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
-@pytest.mark.parametrize("degree", [1, 2, 3])
-def test_lane_fit_matches_oracle(oracle, dtype, degree):
-    A, K, M = 500, 24, 3
-    rng = np.random.default_rng(10 + degree)
+@pytest.mark.parametrize("degree,K", [(1, 24), (2, 24), (3, 24), (0, 7), (3, 8), (2, 33), (3, 64), (1, 65), (3, 150)])
+def test_lane_fit_matches_oracle(oracle, dtype, degree, K):
+    """The point counts cover every form of the kernel: one lane per agent holding all points (K <= 8),
+    four lanes holding 8 or 16 each (K <= 32, 64), and lists read again on every pass (K > 64)."""
+    A, M = 500, 3
+    rng = np.random.default_rng(10 + degree + 100 * (K != 24) * K)
     x0 = rng.uniform(-80, 80, A)
     px = x0[None, :] + np.sort(rng.uniform(-5, 60, (K, A)), axis=0)
     true = rng.normal(0, [5, 0.3, 0.01, 2e-4], (A, 4))[:, :degree + 1]
