@@ -10,6 +10,7 @@ algorithmic bytes reach.
 import argparse
 import os
 import sys
+import time
 
 import numpy as np
 import torch
@@ -70,8 +71,10 @@ def main():
                     gr = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(gr, stream=st):
                         walk()
-                    for _ in range(3):
+                    t0 = time.perf_counter()   # the GPU idled while the host built the ring: let the clocks come back
+                    while time.perf_counter() - t0 < 0.05:
                         gr.replay()
+                        torch.cuda.synchronize()
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record(st)
                     for _ in range(reps):
