@@ -116,12 +116,26 @@ __device__ inline void nearest_in_pass_(const CoursePass<T>& c, T fx, T fy, int 
     // (a few ulps of slack: the box distance and the way-point distance round independently)
     constexpr T kSlack = T(1) + T(8) * Lim<T>::eps;
     const int sups = (runs + kSup - 1) / kSup;
-    unsigned smask = 0u;
-    for (int i = 0; i * G < sups; ++i) {
+    // Every outer box holds a way-point, so the answer is no farther than the far corner of any of
+    // them: for an agent that has left the course far behind (its last target says nothing any
+    // more) this keeps the list to the stretch of the course that faces it.
+    constexpr int kMine = kSups / G;  // outer boxes per lane
+    T d2s[kMine];
+    T far = INFINITY;
+#pragma unroll
+    for (int i = 0; i < kMine; ++i) {
         const int so = i * G + g;  // boxes of runs past the end are empty: infinitely far
-        const T d2 = box_d2_(c.X0[so], c.X1[so], c.Y0[so], c.Y1[so], fx, fy);
-        smask |= (so < sups && d2 <= lim * kSlack) ? 1u << so : 0u;
+        const T X0 = c.X0[so], X1 = c.X1[so], Y0 = c.Y0[so], Y1 = c.Y1[so];
+        d2s[i] = so < sups ? box_d2_(X0, X1, Y0, Y1, fx, fy) : T(INFINITY);
+        const T ex = max_(fx - X0, X1 - fx), ey = max_(fy - Y0, Y1 - fy);
+        far = min_(far, so < sups ? ex * ex + ey * ey : T(INFINITY));
     }
+    far = min_(far, __shfl_xor(far, 1, 64));
+    far = min_(far, __shfl_xor(far, 2, 64));
+    lim = min_(lim, far * kSlack);
+    unsigned smask = 0u;
+#pragma unroll
+    for (int i = 0; i < kMine; ++i) smask |= d2s[i] <= lim * kSlack ? 1u << (i * G + g) : 0u;
     smask = group_or<G>(smask);
     unsigned rlo = 0u, rhi = 0u;  // bit r: run r is listed
     while (smask != 0u) {
