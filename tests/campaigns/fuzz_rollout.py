@@ -157,9 +157,14 @@ def main():
             e = ((tr2[:, :, :3] - tr[:, :, :3]).abs().amax(dim=2) / (1 + tr[:, :, :2].abs().amax(dim=2)))
             calm &= (torch.cummax(e, dim=0).values < calm_lim) & (tr2[:, :, 3] == tr[:, :, 3]).cumprod(dim=0).bool()
         diverged += int((~calm[-1]).sum())
-        dmax = float(torch.where(calm, d, torch.zeros_like(d)).max())
         smis = int(((out["trace"][:, :, 3] != tr[:, :, 3]) & calm).sum())
-        ok_state = calm[-1]
+        judged = calm
+        if args.dtype == "f32":
+            # a verdict on the edge of feasibility may fall either way in single precision (counted in smis and
+            # allowed a few times below); from that tick on the two histories are different loops
+            judged = calm & (out["trace"][:, :, 3] == tr[:, :, 3]).cumprod(dim=0).bool()
+        dmax = float(torch.where(judged, d, torch.zeros_like(d)).max())
+        ok_state = judged[-1]
         ds = float(((lb.state - la.state).double().abs().amax(dim=1) / (1 + la.state.double().abs().amax(dim=1)))[ok_state].max()) if ok_state.any() else 0.0
         di = int((lb.target_idx - la.target_idx)[ok_state].abs().max()) if N and ok_state.any() else 0
         if args.dtype == "f32":     # near-ties between way-points 0.1 m apart, verdicts on the edge of feasibility
@@ -176,13 +181,13 @@ def main():
             ps = np.zeros((A, 2)) if (pid and N) else None
             prm = orc.make_params(alpha=1.0, R=(0.5, 0, 0, 0.5), flags=orc.FLAG_TYPE_PER_AGENT if per_agent else 0)
             tro = np.zeros((T, A, 4))
-            for t in range(T):
+            if N and wps:
+                print("(no host loop: it does not restate way-point speeds)")
+            for t in range(0 if (N and wps) else T):
                 ur = np.zeros((A, 2))
                 if N:
                     ur = orc.nominal_batch(so_, traj, tgt, ps, axle=2.9, k=0.5, ks=0.01, kp=1.0, ki=0.2, kd=0.02, dt=dt,
-                                           target_speed=30 / 3.6) if not wps else None
-                if ur is None:
-                    raise SystemExit("the host loop does not restate way-point speeds")
+                                           target_speed=30 / 3.6)
                 uo, sto, _ = orc.solve_batch(prm, so_, ur, ob_, ty)
                 be = orc.vehicle_step_batch(so_, uo, 1.45, 1.45, np.radians(30.0), dt)
                 tro[t, :, :2], tro[t, :, 2], tro[t, :, 3] = uo, be, sto
@@ -190,10 +195,10 @@ def main():
                     advance(ob_, ty, dt)
                 elif motion == "seeker":
                     seek(ob_, ty, so_[:, :2].copy(), dt, gain, vmin)
-            for name, tt in (("rollout", out["trace"].cpu().numpy()), ("ticks", tr.cpu().numpy())):
+            for name, tt in (() if (N and wps) else (("rollout", out["trace"].cpu().numpy()), ("ticks", tr.cpu().numpy()))):
                 e = np.abs(tt[:, :, :3] - tro[:, :, :3]).max(axis=2) / (1 + np.abs(tro[:, :, :2]).max(axis=2))
                 print("%s against the host loop: per-tick worst %s" % (name, np.array2string(e.max(axis=1), precision=2)))
-            dd = torch.where(calm, d, torch.zeros_like(d))
+            dd = torch.where(judged, d, torch.zeros_like(d))
             a_ = int(dd.amax(dim=0).argmax())
             t_ = int((dd[:, a_] > 1e-9).float().argmax())
             np.set_printoptions(linewidth=200, precision=9)
