@@ -263,6 +263,25 @@ int sccbf_vehicle_step_f64(int64_t A, double* state, const double* u, double lr,
                            double max_steer, double dt, double* beta_out, void* stream);
 
 /*
+ * One control tick's filter and vehicle step in one launch: sccbf_solve_* (reference
+ * cbf/cbf.py:166-220) and then sccbf_vehicle_step_* (State.update_com, reference
+ * test_scripts/stanley_controller_ellipse.py:122-131, called with the filtered input right after
+ * the solve at 760-769) on the input just found.  Arguments as in those two: state T[A][4] is read
+ * by the filter and then overwritten with the stepped state; u_out / status as in sccbf_solve_*;
+ * beta_out T[A] optional.  Dynamics SCCBF_DYN_DBM without SCCBF_FLAG_SLIP_IO only (the step takes
+ * a and delta); anything else: SCCBF_ERR_ARG.  Agents whose status is not optimal are stepped
+ * with the nominal input that u_out then holds, as the two calls would.
+ */
+int sccbf_solve_step_f32(const sccbf_params* p, double max_steer, double dt, int64_t A, int32_t M,
+                         float* state, const float* u_ref, const float* obs,
+                         const uint8_t* obs_type, float* u_out, int32_t* status, float* beta_out,
+                         void* stream);
+int sccbf_solve_step_f64(const sccbf_params* p, double max_steer, double dt, int64_t A, int32_t M,
+                         double* state, const double* u_ref, const double* obs,
+                         const uint8_t* obs_type, double* u_out, int32_t* status, double* beta_out,
+                         void* stream);
+
+/*
  * Closed-loop rollout: `ticks` control ticks of
  *     nominal input (sccbf_nominal_*) -> filter (sccbf_solve_*, DBM) -> vehicle step
  *     (sccbf_vehicle_step_*) -> obstacle motion

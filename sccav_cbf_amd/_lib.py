@@ -21,7 +21,7 @@ EXPORTS = ("sccbf_version", "sccbf_strerror", "sccbf_default_params", "sccbf_sol
            "sccbf_nominal_f64", "sccbf_vehicle_step_f32", "sccbf_vehicle_step_f64",
            "sccbf_default_rollout_params", "sccbf_rollout_f32", "sccbf_rollout_f64",
            "sccbf_solve_sa_f32", "sccbf_solve_sa_f64", "sccbf_ingest_bbox_f32", "sccbf_ingest_bbox_f64",
-           "sccbf_lane_fit_f32", "sccbf_lane_fit_f64")
+           "sccbf_lane_fit_f32", "sccbf_lane_fit_f64", "sccbf_solve_step_f32", "sccbf_solve_step_f64")
 MOTION_STATIC, MOTION_CONSTANT_VELOCITY, MOTION_SEEKER = 0, 1, 2
 NOMINAL_WAYPOINT_SPEED = 1
 
@@ -104,6 +104,10 @@ def load():
         f = getattr(L, name)
         f.restype = C.c_int
         f.argtypes = [C.c_int64, vp, vp, C.c_double, C.c_double, C.c_double, C.c_double, vp, vp]
+    for name in ("sccbf_solve_step_f32", "sccbf_solve_step_f64"):
+        f = getattr(L, name)
+        f.restype = C.c_int
+        f.argtypes = [C.POINTER(Params), C.c_double, C.c_double, C.c_int64, C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp]
     L.sccbf_default_rollout_params.restype = None
     L.sccbf_default_rollout_params.argtypes = [C.POINTER(RolloutParams)]
     for name in ("sccbf_rollout_f32", "sccbf_rollout_f64"):

@@ -70,14 +70,18 @@ class BatchedCBF:
 
     # -- the hot path
     def solve(self, state, u_ref, obs, obs_type, u_out=None, status=None, rows_out=None,
-              want_rows=False, slip=None, dt=None, cone_beta_state=False):
+              want_rows=False, slip=None, dt=None, cone_beta_state=False, step_dt=None,
+              max_steer=np.radians(30.0), beta_out=None):
         """state (A,4), u_ref (A,2), obs (M,2,A,4) [or (ceil(A/64),M,2,64,4): tiles of 64 agents,
         see pack_obs_tiled; or (M,2,4): one table shared by all agents], obs_type uint8 (M,)
         [or (M,A)].  Returns (u_out (A,2), status (A,) int32)
         and, with want_rows/rows_out, rows (M,A,4) = Lg_h0, Lg_h1, b, h.
         dynamics "sadbm": slip (A,2) = beta, beta_ref_last is read and updated in place, dt is the
         time step of this call; cone_beta_state makes every cone take the agent's beta
-        (reference cbf/cbf.py:424-427).  Asynchronous on the current stream."""
+        (reference cbf/cbf.py:424-427).  step_dt (dynamics "dbm", not slip_io, no rows): the same
+        launch then moves every agent by one vehicle step of step_dt with its filtered input, steering
+        clipped to max_steer: state is overwritten, beta_out (A,) optional (nominal.vehicle_step).
+        Asynchronous on the current stream."""
         if not state.is_cuda:
             raise _lib.SccbfError("BatchedCBF.solve needs tensors on the GPU (no CPU fallback)")
         sadbm = self.params.dynamics == _lib.DYN_SADBM
@@ -85,6 +89,8 @@ class BatchedCBF:
             raise ValueError("the steer-rate model needs slip (A,2) and dt")
         if not sadbm and (slip is not None or cone_beta_state):
             raise ValueError("slip / cone_beta_state belong to the steer-rate model (dynamics='sadbm')")
+        if step_dt is not None and (sadbm or want_rows or rows_out is not None):
+            raise ValueError("step_dt goes with the plain solve of the DBM model")
         step = dt
         dt = state.dtype
         if dt not in (torch.float32, torch.float64):
@@ -119,7 +125,8 @@ class BatchedCBF:
         if want_rows and rows_out is None:
             rows_out = torch.empty((M, A, 4), dtype=dt, device=dev)
         for name, t, shape, dtype in (("u_out", u_out, (A, 2), dt), ("status", status, (A,), torch.int32),
-                                      ("rows_out", rows_out, (M, A, 4), dt), ("slip", slip, (A, 2), dt)):
+                                      ("rows_out", rows_out, (M, A, 4), dt), ("slip", slip, (A, 2), dt),
+                                      ("beta_out", beta_out, (A,), dt)):
             if t is not None and (tuple(t.shape) != shape or t.dtype != dtype or t.device != dev
                                   or not t.is_contiguous()):
                 raise ValueError("%s: expected contiguous %s %s on %s" % (name, shape, dtype, dev))
@@ -132,6 +139,10 @@ class BatchedCBF:
                 fn = self._lib.sccbf_solve_sa_f32 if dt == torch.float32 else self._lib.sccbf_solve_sa_f64
                 rc = fn(C.byref(self.params), float(step), A, M, _ptr(state), _ptr(slip), _ptr(u_ref), _ptr(obs),
                         _ptr(obs_type), _ptr(u_out), _ptr(status), _ptr(rows_out), C.c_void_p(stream))
+            elif step_dt is not None:
+                fn = self._lib.sccbf_solve_step_f32 if dt == torch.float32 else self._lib.sccbf_solve_step_f64
+                rc = fn(C.byref(self.params), float(max_steer), float(step_dt), A, M, _ptr(state), _ptr(u_ref),
+                        _ptr(obs), _ptr(obs_type), _ptr(u_out), _ptr(status), _ptr(beta_out), C.c_void_p(stream))
             else:
                 fn = self._lib.sccbf_solve_f32 if dt == torch.float32 else self._lib.sccbf_solve_f64
                 rc = fn(C.byref(self.params), A, M, _ptr(state), _ptr(u_ref), _ptr(obs), _ptr(obs_type),

@@ -63,6 +63,7 @@ int fill_args(const sccbf_params* sp, int64_t A, int32_t M, KArgs<T>& k)
     k.flags = sp->flags;
     k.A = A;
     k.M = M;
+    k.step_state = nullptr; k.step_beta = nullptr; k.step_max_steer = T(0); k.step_dt = T(0);
     return SCCBF_OK;
 }
 
@@ -202,6 +203,35 @@ int solve_impl(const sccbf_params* sp, int64_t A, int32_t M, const T* state, con
         x.slip = nullptr; x.dt = T(0); x.inv_dt = T(0);
         return dispatch_ext<T>(sp, k, x, stream);
     }
+    return dispatch<T, false>(sp, k, stream);
+}
+
+template <typename T>
+int vehicle_step_impl(int64_t A, T* state, const T* u, double lr, double lf, double max_steer, double dt,
+                      T* beta_out, void* stream);
+
+// sccbf_solve_* followed by sccbf_vehicle_step_* on the filtered input, in the same launch
+template <typename T>
+int solve_step_impl(const sccbf_params* sp, double max_steer, double dt, int64_t A, int32_t M, T* state,
+                    const T* u_ref, const T* obs, const uint8_t* obs_type, T* u_out, int32_t* status,
+                    T* beta_out, void* stream)
+{
+    KArgs<T> k;
+    int rc = fill_args<T>(sp, A, M, k);
+    if (rc != SCCBF_OK) return rc;
+    if (sp->dynamics != SCCBF_DYN_DBM || (sp->flags & SCCBF_FLAG_SLIP_IO)) return SCCBF_ERR_ARG;  // the step takes (a, delta)
+    if (!(max_steer >= 0.0) || !std::isfinite(dt)) return SCCBF_ERR_ARG;
+    if (A == 0) return SCCBF_OK;
+    if (!state || !u_ref || !u_out || !status) return SCCBF_ERR_ARG;
+    if (M > 0 && (!obs || !obs_type)) return SCCBF_ERR_ARG;
+    k.state = state; k.u_ref = u_ref; k.obs = obs; k.obs_type = obs_type;
+    k.u_out = u_out; k.status = status; k.rows_out = nullptr;
+    if (M == 0) {  // nothing to filter: the pass-through kernel, then the step
+        rc = dispatch<T, false>(sp, k, stream);
+        if (rc != SCCBF_OK) return rc;
+        return vehicle_step_impl<T>(A, state, u_out, sp->lr, sp->lf, max_steer, dt, beta_out, stream);
+    }
+    k.step_state = state; k.step_beta = beta_out; k.step_max_steer = (T)max_steer; k.step_dt = (T)dt;
     return dispatch<T, false>(sp, k, stream);
 }
 
@@ -442,6 +472,20 @@ int sccbf_lane_fit_f64(int64_t A, int32_t K, int32_t degree, const double* px, c
                        void* stream)
 {
     return lane_fit_impl<double>(A, K, degree, px, py, sigma, buffer, m, M, flags, obs, stream);
+}
+
+int sccbf_solve_step_f32(const sccbf_params* p, double max_steer, double dt, int64_t A, int32_t M, float* state,
+                         const float* u_ref, const float* obs, const uint8_t* obs_type, float* u_out,
+                         int32_t* status, float* beta_out, void* stream)
+{
+    return solve_step_impl<float>(p, max_steer, dt, A, M, state, u_ref, obs, obs_type, u_out, status, beta_out, stream);
+}
+
+int sccbf_solve_step_f64(const sccbf_params* p, double max_steer, double dt, int64_t A, int32_t M, double* state,
+                         const double* u_ref, const double* obs, const uint8_t* obs_type, double* u_out,
+                         int32_t* status, double* beta_out, void* stream)
+{
+    return solve_step_impl<double>(p, max_steer, dt, A, M, state, u_ref, obs, obs_type, u_out, status, beta_out, stream);
 }
 
 int sccbf_version(void) { return SCCBF_VERSION; }

@@ -63,6 +63,10 @@ template <typename T> struct KArgs {
     T* u_out;
     int* status;
     T* rows_out;
+    // vehicle step on the filtered input after the solve (null: none), sccbf_solve_step_*
+    T* step_state;
+    T* step_beta;
+    T step_max_steer, step_dt;
 };
 
 // ------------------------------------------------------------------ math shims

@@ -256,23 +256,7 @@ __global__ __launch_bounds__(kNomBlock) void k_nominal(const NArgs<T> p)
     }
 }
 
-// ------------------------------------------------------- vehicle step (update_com)
-// State.update_com, reference test_scripts/stanley_controller_ellipse.py:122-131; returns beta.
-template <typename T>
-__device__ inline T vehicle_step_(typename VT<T>::v4& s, T acc, T delta_in, T k_in, T inv_lr, T max_steer, T dt)
-{
-    const T delta = min_(max_(delta_in, -max_steer), max_steer);
-    const T beta = atan_(tan_(delta) * k_in);  // atan2(lr tan(delta), lf + lr), lf + lr > 0
-    T sth, cth;
-    sincos_(s.z, &sth, &cth);
-    const T v = s.w;
-    s.x += (v * cth - v * sth * beta) * dt;
-    s.y += (v * sth + v * cth * beta) * dt;
-    s.z += (v * beta * inv_lr) * dt;
-    s.w += acc * dt;
-    return beta;
-}
-
+// ------------------------------------------------------- vehicle step (update_com): vehicle_step_ in sccbf_rows.hip.h
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_vehicle_step(long long A, T* state, const T* u, T k_in,
                                                          T inv_lr, T max_steer, T dt, T* beta_out)

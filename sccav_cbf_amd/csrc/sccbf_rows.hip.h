@@ -285,13 +285,40 @@ __device__ inline typename VT<T>::v2 result_u_(const KArgs<T>& p, bool qp_only, 
     return out;
 }
 
+// ------------------------------------------------------- vehicle step (update_com)
+// State.update_com, reference test_scripts/stanley_controller_ellipse.py:122-131; returns beta.
+template <typename T>
+__device__ inline T vehicle_step_(typename VT<T>::v4& s, T acc, T delta_in, T k_in, T inv_lr, T max_steer, T dt)
+{
+    const T delta = min_(max_(delta_in, -max_steer), max_steer);
+    const T beta = atan_(tan_(delta) * k_in);  // atan2(lr tan(delta), lf + lr), lf + lr > 0
+    T sth, cth;
+    sincos_(s.z, &sth, &cth);
+    const T v = s.w;
+    s.x += (v * cth - v * sth * beta) * dt;
+    s.y += (v * sth + v * cth * beta) * dt;
+    s.z += (v * beta * inv_lr) * dt;
+    s.w += acc * dt;
+    return beta;
+}
+
+// The lane that holds the answer stores it and, where the caller asked for it (sccbf_solve_step_*),
+// moves the agent by one vehicle step with the filtered input.
 template <typename T>
 __device__ inline void store_result_(const KArgs<T>& p, long long qp, bool qp_only, int st,
                                      T w0, T w1, const Ego<T>& e, T ur0, T ur1)
 {
     using v2 = typename VT<T>::v2;
-    reinterpret_cast<v2*>(p.u_out)[qp] = result_u_(p, qp_only, st, w0, w1, e, ur0, ur1);
+    using v4 = typename VT<T>::v4;
+    const v2 u = result_u_(p, qp_only, st, w0, w1, e, ur0, ur1);
+    reinterpret_cast<v2*>(p.u_out)[qp] = u;
     p.status[qp] = st;
+    if (p.step_state) {
+        v4 s = v4{e.x, e.y, e.th, e.v};
+        const T beta = vehicle_step_<T>(s, u.x, u.y, p.k_in, p.inv_lr, p.step_max_steer, p.step_dt);
+        reinterpret_cast<v4*>(p.step_state)[qp] = s;
+        if (p.step_beta) p.step_beta[qp] = beta;
+    }
 }
 
 }  // namespace

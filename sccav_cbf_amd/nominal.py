@@ -185,6 +185,11 @@ class ClosedLoop:
         if self.slip is not None:
             self.cbf.solve(self.state, self.u_ref, self.obs, self.obs_type, u_out=self.u, status=self.status,
                            slip=self.slip, dt=self.dt, cone_beta_state=True)
+        elif self.cbf.params.dynamics == _lib.DYN_DBM and not self.cbf.slip_io:
+            # filter and vehicle step in one launch
+            self.cbf.solve(self.state, self.u_ref, self.obs, self.obs_type, u_out=self.u, status=self.status,
+                           step_dt=self.dt, max_steer=self.max_steer, beta_out=self.beta)
+            return
         else:
             self.cbf.solve(self.state, self.u_ref, self.obs, self.obs_type, u_out=self.u, status=self.status)
         vehicle_step(self.state, self.u, lr=self.cbf.params.lr, lf=self.cbf.params.lf,

@@ -143,6 +143,25 @@ def test_model_variants_argument_validation(lib):
     assert lib.sccbf_solve_sa_f64(None, 0.1, 0, 4, *nul9) == -1
 
 
+def test_solve_step_argument_validation(lib):
+    p = _lib.Params()
+    lib.sccbf_default_params(C.byref(p))
+    nul8 = (C.c_void_p(0),) * 8
+    ss = lambda ms, dt, A, M: lib.sccbf_solve_step_f32(C.byref(p), ms, dt, A, M, *nul8)    # noqa: E731
+    assert ss(0.5, 0.1, 0, 4) == 0
+    assert ss(0.5, 0.1, 8, 4) == -1                                      # null data
+    assert ss(-0.1, 0.1, 0, 4) == -1 and ss(float("nan"), 0.1, 0, 4) == -1 and ss(0.5, float("inf"), 0, 4) == -1
+    assert ss(0.5, 0.1, 0, 1025) == -2
+    for dyn in (_lib.DYN_KBM, _lib.DYN_DUM, _lib.DYN_SADBM):             # the step is the DBM drivers' update_com
+        p.dynamics = dyn
+        assert ss(0.5, 0.1, 0, 4) == -1
+    p.dynamics = _lib.DYN_DBM
+    p.flags = _lib.FLAG_SLIP_IO                                          # the step takes a steering angle
+    assert ss(0.5, 0.1, 0, 4) == -1
+    p.flags = 0
+    assert lib.sccbf_solve_step_f64(None, 0.5, 0.1, 0, 4, *nul8) == -1
+
+
 def test_ingest_and_lane_fit_argument_validation(lib):
     nul = C.c_void_p(0)
     ing = lambda A, M, buf=0.5, flags=0: lib.sccbf_ingest_bbox_f32(A, M, nul, nul, buf, flags, nul, nul)

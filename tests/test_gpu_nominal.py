@@ -422,3 +422,41 @@ def test_nonfinite_and_diverged_states_do_not_disturb_their_neighbours(dtype):
     assert torch.equal(dirty.state[good], clean.state[good])
     st0 = out["trace"][0, bad, 3]
     assert (st0[[0, 1, 3, 4]] == 2).all()          # non-finite state: flagged on the first tick
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("lanes,M,tiled", [(0, 16, True), (4, 16, False), (16, 5, True), (64, 16, False), (0, 300, False), (0, 0, False)])
+def test_solve_step_is_solve_then_vehicle_step(dtype, lanes, M, tiled):
+    """The fused tick (filter + vehicle step in one launch) against the two launches: same inputs and
+    verdicts bit for bit, the stepped state and slip angle to rounding (the step is compiled into a
+    different kernel)."""
+    from sccav_cbf_amd import scenarios
+    from sccav_cbf_amd.batched import BatchedCBF, planes_to_tiled
+    from sccav_cbf_amd.nominal import vehicle_step
+    A = 3000
+    w = scenarios.config4(A=A, seed=31)
+    reps = -(-max(M, 1) // 16)
+    obs = torch.from_numpy(np.tile(w["obs"], (reps, 1, 1, 1))[:M].copy()).to(dtype).to(DEV)
+    ty = torch.from_numpy(np.tile(w["obs_type"], reps)[:M].copy()).to(DEV)
+    if tiled:
+        obs = planes_to_tiled(obs)
+    state = torch.from_numpy(w["state"]).to(dtype).to(DEV)
+    u_ref = torch.from_numpy(w["u_ref"]).to(dtype).to(DEV)
+    f = BatchedCBF(alpha=1.0, R=np.diag([0.5, 0.5]), lanes_per_qp=lanes)
+    u0, st0 = f.solve(state, u_ref, obs, ty)
+    s0 = state.clone()
+    b0 = torch.empty(A, dtype=dtype, device=DEV)
+    vehicle_step(s0, u0, max_steer=np.radians(30.0), dt=0.1, beta_out=b0)
+    s1 = state.clone()
+    b1 = torch.empty(A, dtype=dtype, device=DEV)
+    u1, st1 = f.solve(s1, u_ref, obs, ty, step_dt=0.1, max_steer=np.radians(30.0), beta_out=b1)
+    torch.cuda.synchronize()
+    assert torch.equal(st0, st1)
+    assert torch.equal(u0, u1)
+    fin = torch.isfinite(s0).all(dim=1)
+    assert torch.equal(fin, torch.isfinite(s1).all(dim=1))
+    tol = 1e-13 if dtype == torch.float64 else 1e-6
+    scale = 1 + s0[fin].abs().amax(dim=1, keepdim=True)
+    assert ((s1[fin] - s0[fin]).abs() / scale).max() <= tol
+    assert (b1[fin] - b0[fin]).abs().max() <= tol
+    assert not torch.equal(s1, state)
