@@ -34,6 +34,10 @@ int main()
     expect(sccbf_nominal_f64(0, 4, 10, 0, 0, 0, 0, 0, 0), -1, "nominal null params");
     expect(sccbf_vehicle_step_f32(0, 0, 0, 1.45, 1.45, 0.5, 0.1, 0, 0), 0, "step empty");
     expect(sccbf_vehicle_step_f64(4, 0, 0, 0.0, 1.45, 0.5, 0.1, 0, 0), -1, "step lr");
+    expect(sccbf_solve_step_f32(&p, 0.5, 0.1, 0, 4, 0, 0, 0, 0, 0, 0, 0, 0), 0, "solve_step empty");
+    expect(sccbf_solve_step_f64(&p, 0.5, 0.1, 8, 4, 0, 0, 0, 0, 0, 0, 0, 0), -1, "solve_step null");
+    expect(sccbf_solve_step_f64(&p, -1.0, 0.1, 0, 4, 0, 0, 0, 0, 0, 0, 0, 0), -1, "solve_step max_steer");
+    expect(sccbf_solve_step_f32(0, 0.5, 0.1, 0, 4, 0, 0, 0, 0, 0, 0, 0, 0), -1, "solve_step null params");
     rp.ticks = 3;
     expect(sccbf_rollout_f32(&p, &np, &rp, 0, 4, 10, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0), 0, "rollout empty");
     expect(sccbf_rollout_f64(&p, &np, &rp, 4, 65, 10, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0), -2, "rollout slots");
