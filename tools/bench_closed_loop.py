@@ -99,6 +99,22 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         t_roll_cv = e0.elapsed_time(e1) * 1e3 / (reps * T)
+        # one tick per launch through the rollout kernel (nominal + filter + step in one launch, the
+        # obstacles re-read every tick as when the host moves them in between)
+        loop.state.copy_(state0)
+        loop.target_idx.zero_()
+        out1 = loop.rollout(1, trace=True)
+        torch.cuda.synchronize()
+        g1 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g1, stream=st):
+            loop.state.copy_(state0)
+            loop.target_idx.zero_()
+            for _ in range(10):
+                loop.rollout(1, trace=True, out=out1)
+        t_one = timed(g1.replay, 50) / 10
+    print("   one-tick rollout launches, captured: %.2f us per tick" % t_one)
+    with torch.cuda.stream(st):
+        pass
     print("   fused rollout (%d ticks per launch): %.2f us per tick (%.3e agent-ticks/s); with moving obstacles %.2f us"
           % (T, t_roll, A / (t_roll * 1e-6), t_roll_cv))
     with torch.cuda.stream(st):
