@@ -120,8 +120,12 @@ def main():
             for _ in range(T):
                 if N:
                     la.nominal.control(la.state, la.traj, la.target_idx, la.pid_state, u_ref=la.u_ref)
-                u, st = la.cbf.solve(la.state, la.u_ref, la.obs, la.obs_type, u_out=la.u, status=la.status)
-                vehicle_step(la.state, la.u, lr=1.45, lf=1.45, max_steer=la.max_steer, dt=dt, beta_out=la.beta)
+                if case % 2:    # odd cases: filter and vehicle step in one launch (sccbf_solve_step_*)
+                    u, st = la.cbf.solve(la.state, la.u_ref, la.obs, la.obs_type, u_out=la.u, status=la.status,
+                                         step_dt=dt, max_steer=la.max_steer, beta_out=la.beta)
+                else:
+                    u, st = la.cbf.solve(la.state, la.u_ref, la.obs, la.obs_type, u_out=la.u, status=la.status)
+                    vehicle_step(la.state, la.u, lr=1.45, lf=1.45, max_steer=la.max_steer, dt=dt, beta_out=la.beta)
                 tr.append(torch.cat([u, la.beta[:, None], st.to(dt_t)[:, None]], dim=1).double())
                 if motion == "constant_velocity":
                     advance(host, ty, dt)
