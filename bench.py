@@ -11,10 +11,17 @@ HBM before the timed region; the steps walk a ring of distinct batches larger th
 batches (weak scaling, no data-path collective).  Rank 0 prints ONE JSON line.
 Order: untimed clock ramp (--ramp-ms of work, an idle GPU is slow for its first milliseconds),
 W untimed warm-up steps, barrier, exactly K timed steps, barrier.
+
+--gpus N with N > 1 and no WORLD_SIZE in the environment: this process touches no GPU, starts N
+fresh rank processes (one per GPU, RCCL through torch.distributed "nccl") and relays rank 0's
+line; it exits non-zero if fewer than N devices are visible or any rank fails.  Under a launcher
+that sets WORLD_SIZE (torch.distributed.run) the process is a rank and --gpus must equal WORLD_SIZE.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,7 +32,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from sccav_cbf_amd import scenarios  # noqa: E402
-from sccav_cbf_amd.batched import BatchedCBF, planes_to_tiled  # noqa: E402
 
 AGENTS = 65536
 ROWS = 16
@@ -38,7 +44,8 @@ def algorithmic_bytes(A, M, w=4):
     return A * (w * (4 + 2 + 8 * M + 2) + 4)
 
 
-def make_ring(rank, device, n=RING, agents=AGENTS, tiled=True):
+def make_ring(rank, device, n=RING, agents=AGENTS, layout="tiles"):
+    from sccav_cbf_amd.batched import planes_to_tiled
     ring = []
     for b in range(n):
         w = scenarios.config4(A=agents, seed=1234 + 4 + 1000 * rank + b)
@@ -48,30 +55,43 @@ def make_ring(rank, device, n=RING, agents=AGENTS, tiled=True):
                  obs_type=torch.from_numpy(w["obs_type"]).to(device),
                  u_out=torch.empty((agents, 2), dtype=torch.float32, device=device),
                  status=torch.empty((agents,), dtype=torch.int32, device=device))
-        if tiled:   # tiles of 64 agents: (A/64, M, 2, 64, 4)
+        if layout == "tiles":   # tiles of 64 agents: (A/64, M, 2, 64, 4)
             t["obs"] = planes_to_tiled(t["obs"])
         ring.append(t)
     return ring
 
 
 def cpu_baseline(seconds=10.0):
-    """The fp64 oracle (OpenMP) on the host cores, on the first batch of the ring."""
+    """The fp64 oracle on the host cores, on the first batch of the ring: OpenMP on the threads this
+    process may use (OMP_NUM_THREADS where the box sets it, else every core), and one thread."""
     from oracle import oracle as orc
     orc.build()
-    threads = min(16, os.cpu_count() or 1)
-    os.environ.setdefault("OMP_NUM_THREADS", str(threads))
-    threads = int(os.environ["OMP_NUM_THREADS"])
+    host_cores = os.cpu_count() or 1
+    threads = int(os.environ.get("OMP_NUM_THREADS", host_cores))
     w = scenarios.config4(A=AGENTS, seed=1234 + 4)
     p = orc.make_params(alpha=1.0, R=(0.5, 0, 0, 0.5))
-    orc.solve_batch(p, w["state"], w["u_ref"], w["obs"], w["obs_type"])  # warm
-    n, t0 = 0, time.perf_counter()
-    while time.perf_counter() - t0 < seconds:
-        orc.solve_batch(p, w["state"], w["u_ref"], w["obs"], w["obs_type"])
-        n += 1
-    dt = time.perf_counter() - t0
-    out = {"value": n * AGENTS / dt, "unit": "solves/s", "cores": threads, "kind": "port",
-           "sample": "%d passes of the fp64 C oracle (OpenMP, %d threads) over one 65536-agent x 16-row "
-                     "batch, %.1f s" % (n, threads, dt)}
+    omp = orc.lib()   # liboracle.so links libgomp: its symbols resolve through the same handle
+
+    def timed(nthreads, budget, agents):
+        omp.omp_set_num_threads(int(nthreads))
+        st, ur = w["state"][:agents], w["u_ref"][:agents]
+        ob = np.ascontiguousarray(w["obs"][:, :, :agents, :])
+        orc.solve_batch(p, st, ur, ob, w["obs_type"])  # warm
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < budget:
+            orc.solve_batch(p, st, ur, ob, w["obs_type"])
+            n += 1
+        dt = time.perf_counter() - t0
+        return n * agents / dt, n, dt
+
+    v, n, dt = timed(threads, seconds, AGENTS)
+    v1, n1, dt1 = timed(1, 0.4 * seconds, AGENTS // 8)
+    omp.omp_set_num_threads(threads)
+    out = {"value": v, "unit": "solves/s", "cores": threads, "threads": threads, "host_cores": host_cores,
+           "value_1thread": v1, "kind": "port",
+           "sample": "%d passes of the fp64 C oracle (OpenMP, %d threads of %d host cores) over one "
+                     "65536-agent x 16-row batch, %.1f s; one thread: %d passes over 8192 agents, %.1f s"
+                     % (n, threads, host_cores, dt, n1, dt1)}
     # the reference hands every QP to an interpreted general-purpose solver (cvxopt.solvers.cp,
     # cbf/cbf.py:213); cvxopt is not installed here, so scipy's SLSQP on the same rows stands in
     try:
@@ -104,18 +124,48 @@ def slsqp_proxy(orc, p, w, n_qp=192, budget=6.0):
             "sample": "%d QPs, %.1f s" % (done, dt)}
 
 
-def large_batch(flt, device, agents=1 << 20, n=3, reps=60):
+def _profile_json(name):
+    """A number kept from a counter run of this same workload (profiles/*.json), or None."""
+    path = os.path.join(ROOT, "profiles", name)
+    try:
+        return json.load(open(path)).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def _time_graph(walk, stream, n_per_walk, reps):
+    """us per launch of walk() (n_per_walk launches) replayed from a hipGraph on `stream`."""
+    walk()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=stream):
+        walk()
+    for _ in range(reps):   # the GPU idled while the host built the batch: let the clocks come back
+        g.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(reps):
+        g.replay()
+    e1.record(stream)
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / (reps * n_per_walk)   # ms per launch
+
+
+def large_batch(flt, device, layout, agents=1 << 20, n=3, reps=60):
     """The same kernel on 2^20 agents per launch (not part of `value`): at that size a launch is
     no longer dominated by its start-up and tail.  The ring re-uses one C4 batch rotated by whole
     tiles: 3 x 575 MB, more than twice the Infinity Cache."""
+    from sccav_cbf_amd.batched import planes_to_tiled
     w = scenarios.config4(A=agents, seed=99)
     ring = []
     for b in range(n):
         sh = 64 * 1237 * (b + 1)
+        obs = torch.from_numpy(np.roll(w["obs"], sh, axis=2)).float().to(device)
         ring.append(dict(
             state=torch.from_numpy(np.roll(w["state"], sh, axis=0)).float().to(device),
             u_ref=torch.from_numpy(np.roll(w["u_ref"], sh, axis=0)).float().to(device),
-            obs=planes_to_tiled(torch.from_numpy(np.roll(w["obs"], sh, axis=2)).float().to(device)),
+            obs=planes_to_tiled(obs) if layout == "tiles" else obs,
             u_out=torch.empty((agents, 2), dtype=torch.float32, device=device),
             status=torch.empty((agents,), dtype=torch.int32, device=device)))
     ty = torch.from_numpy(w["obs_type"]).to(device)
@@ -124,25 +174,324 @@ def large_batch(flt, device, agents=1 << 20, n=3, reps=60):
         def walk():
             for b in ring:
                 flt.solve(b["state"], b["u_ref"], b["obs"], ty, u_out=b["u_out"], status=b["status"])
-        walk()
-        torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, stream=st):
-            walk()
-        for _ in range(reps):   # the GPU idled while the host built the batch: let the clocks come back
-            g.replay()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(st)
-        for _ in range(reps):
-            g.replay()
-        e1.record(st)
-        torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / (reps * n)
+        ms = _time_graph(walk, st, n, reps)
     ab = algorithmic_bytes(agents, ROWS)
     return {"agents": agents, "kernel_ms": ms, "solves_per_s": agents / (ms * 1e-3),
             "achieved_GBps": ab / (ms * 1e-3) / 1e9, "frac": ab / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+            "algorithmic_bytes_per_launch": ab, "traffic": _profile_json("traffic_large.json"),
             "launches": reps * n}
+
+
+def fp64_lines(device):
+    """The reference computes in fp64 throughout: the same filter in fp64 on the two fp64 shapes the
+    configurations name, priced like the fp32 line (68 + 64 M bytes per QP).
+    c5: 16384 agents x (2 lanes + 6 cones), ring of 30 rotations of one batch (> 256 MiB);
+    c2: 1 ego x 32 radial obstacles, one wavefront for the QP: a launch-latency case."""
+    from sccav_cbf_amd.batched import BatchedCBF, planes_to_tiled
+    out = {}
+    flt = BatchedCBF(alpha=1.0, lr=1.45, lf=1.45, R=np.diag([0.5, 0.5]))
+    st = torch.cuda.Stream(device)
+    with torch.cuda.stream(st):
+        A, n = 16384, 30
+        w = scenarios.lanes_and_cones(A=A)
+        M = w["obs"].shape[0]
+        ty = torch.from_numpy(w["obs_type"]).to(device)
+        ring = []
+        for b in range(n):
+            sh = 64 * 37 * (b + 1)
+            ring.append(dict(
+                state=torch.from_numpy(np.roll(w["state"], sh, axis=0)).to(device),
+                u_ref=torch.from_numpy(np.roll(w["u_ref"], sh, axis=0)).to(device),
+                obs=planes_to_tiled(torch.from_numpy(np.roll(w["obs"], sh, axis=2)).to(device)),
+                u_out=torch.empty((A, 2), dtype=torch.float64, device=device),
+                status=torch.empty((A,), dtype=torch.int32, device=device)))
+
+        def walk():
+            for b in ring:
+                flt.solve(b["state"], b["u_ref"], b["obs"], ty, u_out=b["u_out"], status=b["status"])
+        ms = _time_graph(walk, st, n, 40)
+        ab = algorithmic_bytes(A, M, w=8)
+        out["c5"] = {"workload": "C5 fp64: %d agents x %d rows (2 lanes + 6 cones)" % (A, M), "kernel_ms": ms,
+                     "solves_per_s": A / (ms * 1e-3), "algorithmic_bytes_per_launch": ab,
+                     "achieved_GBps": ab / (ms * 1e-3) / 1e9, "frac": ab / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+        del ring
+        w = scenarios.radial_seekers(M=32)
+        t = {k: torch.from_numpy(v).to(device) for k, v in w.items()}
+        uo = torch.empty((1, 2), dtype=torch.float64, device=device)
+        so = torch.empty((1,), dtype=torch.int32, device=device)
+
+        def walk2():
+            for _ in range(10):
+                flt.solve(t["state"], t["u_ref"], t["obs"], t["obs_type"], u_out=uo, status=so)
+        ms = _time_graph(walk2, st, 10, 200)
+        out["c2"] = {"workload": "C2 fp64: 1 ego x 32 radial rows", "kernel_ms": ms,
+                     "note": "launch latency, not bandwidth: one QP per launch"}
+    return out
+
+
+# ------------------------------------------------------------------------------ launcher
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launcher(args, argv):
+    """Start args.gpus rank processes of this script and relay rank 0's JSON line.  This process has
+    made no GPU call (counting devices does not initialise the runtime) and makes none."""
+    n = args.gpus
+    if not args.cpu_stub:
+        have = torch.cuda.device_count()
+        if have < n:
+            print("bench.py: --gpus %d asked for, %d GPU(s) visible: not running a smaller job under that "
+                  "name" % (n, have), file=sys.stderr)
+            return 2
+    env = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=e,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    # a rank that dies leaves the others waiting in a collective: end them with it
+    deadline = time.time() + args.launch_timeout
+    codes = [None] * n
+    while any(c is None for c in codes):
+        for i, p in enumerate(procs):
+            if codes[i] is None:
+                codes[i] = p.poll()
+        failed = [c for c in codes if c not in (None, 0)]
+        if failed or time.time() > deadline:
+            for i, p in enumerate(procs):
+                if codes[i] is None:
+                    p.kill()
+            for i, p in enumerate(procs):
+                if codes[i] is None:
+                    codes[i] = p.wait()
+            print("bench.py: rank exit codes %s%s" % (codes, "" if failed else " (timed out)"), file=sys.stderr)
+            return 1
+        if any(c is None for c in codes):
+            time.sleep(0.05)
+    line = procs[0].stdout.read().decode()
+    last = [ln for ln in line.splitlines() if ln.strip()]
+    if not last:
+        print("bench.py: rank 0 printed nothing", file=sys.stderr)
+        return 1
+    out = json.loads(last[-1])
+    if out.get("n_gpus") != n:
+        print("bench.py: rank 0 reports n_gpus=%r, expected %d" % (out.get("n_gpus"), n), file=sys.stderr)
+        return 1
+    print(last[-1], flush=True)
+    return 0
+
+
+# -------------------------------------------------------------------------------- a rank
+def worker(args):
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d: launch one rank per GPU (or leave WORLD_SIZE unset and "
+              "let --gpus start them)" % (args.gpus, world), file=sys.stderr)
+        return 2
+    stub = args.cpu_stub
+    dist = None
+    if stub:
+        device = torch.device("cpu")
+    else:
+        if torch.cuda.device_count() <= local:
+            print("bench.py: rank %d needs GPU %d, %d visible" % (rank, local, torch.cuda.device_count()),
+                  file=sys.stderr)
+            return 2
+        device = torch.device("cuda", local)
+        torch.cuda.set_device(device)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if stub:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
+        if dist.get_world_size() != world:
+            print("bench.py: process group has %d ranks, expected %d" % (dist.get_world_size(), world),
+                  file=sys.stderr)
+            return 2
+
+    A, M = args.agents, ROWS
+    if stub:
+        # launcher / collective plumbing rehearsal on the CPU: the "solve" is a copy, nothing is measured
+        ring = [dict(u_ref=torch.zeros((A, 2)), u_out=torch.empty((A, 2)),
+                     status=torch.zeros((A,), dtype=torch.int32)) for _ in range(RING)]
+
+        def step(i):
+            b = ring[i % RING]
+            b["u_out"].copy_(b["u_ref"])
+        sync = (lambda: None)
+        flt = None
+    else:
+        from sccav_cbf_amd.batched import BatchedCBF
+        flt = BatchedCBF(alpha=1.0, lr=1.45, lf=1.45, R=np.diag([0.5, 0.5]), lanes_per_qp=args.lanes)
+        ring = make_ring(rank, device, agents=A, layout=args.layout)
+
+        def step(i):
+            b = ring[i % RING]
+            flt.solve(b["state"], b["u_ref"], b["obs"], b["obs_type"], u_out=b["u_out"], status=b["status"])
+        sync = torch.cuda.synchronize
+
+    def barrier():
+        sync()
+        if dist is not None:
+            dist.barrier()
+        sync()
+
+    # one hipGraph = one walk over the ring; eager launches cover the remainder
+    graph = None
+    ramp_steps = 0
+    if stub:
+        for i in range(args.warmup):
+            step(i)
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(i)
+        barrier()
+        wall = time.perf_counter() - t0
+        dev_ms = wall * 1e3
+    else:
+        stream = torch.cuda.Stream(device)
+        with torch.cuda.stream(stream):
+            for i in range(RING):
+                step(i)
+            torch.cuda.synchronize()
+            if not args.no_graph:
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=stream):
+                    for i in range(RING):
+                        step(i)
+
+            def run(k):
+                done = 0
+                if graph is not None:
+                    for _ in range(k // RING):
+                        graph.replay()
+                    done = (k // RING) * RING
+                for i in range(done, k):
+                    step(i)
+
+            # An idle GPU needs some ten milliseconds of work to reach its clocks, more than a short
+            # warm-up gives it: untimed walks over the ring first, then the W warm-up steps.
+            t_ramp = time.perf_counter()
+            while (time.perf_counter() - t_ramp) * 1e3 < args.ramp_ms:
+                run(10 * RING)
+                torch.cuda.synchronize()
+                ramp_steps += 10 * RING
+            run(args.warmup)
+            barrier()
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0 = time.perf_counter()
+            ev0.record(stream)
+            run(args.steps)
+            ev1.record(stream)
+            barrier()
+            t1 = time.perf_counter()
+            wall = t1 - t0
+            dev_ms = ev0.elapsed_time(ev1)
+
+    # max over ranks of the timed region; every rank's own time; proof that the collective
+    # library saw every rank (a sum of ones over the process group)
+    rank_ms = [wall / args.steps * 1e3]
+    coll_ranks = 1
+    if dist is not None:
+        tw = torch.tensor([wall], dtype=torch.float64, device=device)
+        allw = torch.empty((world,), dtype=torch.float64, device=device)
+        dist.all_gather_into_tensor(allw, tw)
+        one = torch.ones((1,), dtype=torch.int32, device=device)
+        dist.all_reduce(one, op=dist.ReduceOp.SUM)
+        sync()
+        rank_ms = [float(x) / args.steps * 1e3 for x in allw.cpu()]
+        wall = float(allw.max().item())
+        coll_ranks = int(one.item())
+
+    # Outside the timed region: what collecting every rank's answers costs per step (the solve
+    # itself never communicates).  all_gather of u_out (A,2) f32 and status (A,) i32.
+    gather_ms = None
+    if dist is not None:
+        gu = torch.empty((world * A, 2), dtype=torch.float32, device=device)
+        gs = torch.empty((world * A,), dtype=torch.int32, device=device)
+        reps = 20
+        for i in range(3 + reps):
+            if i == 3:
+                sync()
+                tg = time.perf_counter()
+            dist.all_gather_into_tensor(gu, ring[0]["u_out"])
+            dist.all_gather_into_tensor(gs, ring[0]["status"])
+        sync()
+        tg = torch.tensor([(time.perf_counter() - tg) / reps * 1e3], dtype=torch.float64, device=device)
+        dist.all_reduce(tg, op=dist.ReduceOp.MAX)
+        gather_ms = float(tg.item())
+
+    status = torch.stack([b["status"] for b in ring]).cpu().numpy()
+    counts = np.bincount(status.reshape(-1), minlength=3)
+
+    rc = 0
+    if rank == 0:
+        total_solves = A * args.steps * world
+        value = total_solves / wall
+        kern_ms = dev_ms / args.steps           # device time per step over the timed region
+        abytes = algorithmic_bytes(A, M)
+        achieved = abytes / (kern_ms * 1e-3) / 1e9
+        layout_name = {"tiles": "tiles (A/64,M,2,64,4)", "planes": "planes (M,2,A,4)"}[args.layout]
+        out = {
+            "metric": "CBF-QP solves/sec (2-input, 16-constraint)",
+            "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "C4: %d agents x 16 obstacle rows (8 ellipse + 8 collision cone) per GPU, "
+                                   "DBM filter, alpha=1, R=diag(.5,.5), ring of %d distinct batches" % (A, RING),
+                       "agents_per_gpu": A, "rows": M, "lanes_per_qp": args.lanes,
+                       "obs_layout": layout_name,
+                       "launch": "eager" if graph is None else "hipGraph of %d launches" % RING,
+                       "clock_ramp_steps_before_warmup": ramp_steps},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": _profile_json("traffic.json"),
+                         "kernel_ms": kern_ms,
+                         "algorithmic_bytes_per_launch": abytes},
+            "status_counts": {"optimal": int(counts[0]), "infeasible": int(counts[1]),
+                              "nonfinite": int(counts[2])},
+            # QPs whose rows admit no input: the filter reports status 1 and hands back the nominal input
+            "infeasible_fraction": float(counts[1]) / max(1, int(counts.sum())),
+        }
+        if stub:
+            out["data"] = "none (cpu stub: launcher rehearsal, nothing measured)"
+            out["stub"] = True
+            out["roofline"] = None
+        if world > 1:
+            out["rccl_ranks" if not stub else "gloo_ranks"] = coll_ranks
+            out["ms_per_step_by_rank"] = rank_ms
+            out["gather_ms_per_step"] = gather_ms   # not part of value / ms_per_step
+            if coll_ranks != world:
+                print("bench.py: the collective saw %d ranks, expected %d" % (coll_ranks, world), file=sys.stderr)
+                rc = 1
+        if world == 1 and not stub and not args.no_large and A == AGENTS:
+            try:
+                del ring
+                torch.cuda.empty_cache()
+                out["roofline_large_batch"] = large_batch(flt, device, args.layout)
+            except Exception as e:  # extra information only
+                out["roofline_large_batch"] = {"error": repr(e)}
+        if world == 1 and not stub and not args.no_fp64 and A == AGENTS:
+            try:
+                out["fp64"] = fp64_lines(device)
+            except Exception as e:
+                out["fp64"] = {"error": repr(e)}
+        if world == 1 and not stub and not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    return rc
 
 
 def main():
@@ -156,155 +505,20 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
     ap.add_argument("--planes", action="store_true", help="obstacles as (M,2,A,4) planes instead of 64-agent tiles")
     ap.add_argument("--no-large", action="store_true", help="skip the extra 1M-agent measurement (N=1 only)")
+    ap.add_argument("--no-fp64", action="store_true", help="skip the fp64 lines (N=1 only)")
     ap.add_argument("--ramp-ms", type=float, default=60.0,
                     help="untimed work ahead of the warm-up steps that lets an idle GPU reach its clocks")
+    ap.add_argument("--cpu-stub", action="store_true",
+                    help="rehearse launcher and collectives on the CPU (gloo, the solve is a copy): measures nothing")
+    ap.add_argument("--launch-timeout", type=float, default=900.0, help="seconds the --gpus launcher waits for its ranks")
     args = ap.parse_args()
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    device = torch.device("cuda", local)
-    torch.cuda.set_device(device)
-
-    A, M = args.agents, ROWS
-    flt = BatchedCBF(alpha=1.0, lr=1.45, lf=1.45, R=np.diag([0.5, 0.5]), lanes_per_qp=args.lanes)
-    ring = make_ring(rank, device, agents=A, tiled=not args.planes)
-
-    def step(i):
-        b = ring[i % RING]
-        flt.solve(b["state"], b["u_ref"], b["obs"], b["obs_type"], u_out=b["u_out"], status=b["status"])
-
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    # one hipGraph = one walk over the ring; eager launches cover the remainder
-    graph = None
-    stream = torch.cuda.Stream(device)
-    with torch.cuda.stream(stream):
-        for i in range(RING):
-            step(i)
-        torch.cuda.synchronize()
-        if not args.no_graph:
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=stream):
-                for i in range(RING):
-                    step(i)
-
-        def run(k):
-            done = 0
-            if graph is not None:
-                for _ in range(k // RING):
-                    graph.replay()
-                done = (k // RING) * RING
-            for i in range(done, k):
-                step(i)
-
-        # An idle GPU needs some ten milliseconds of work to reach its clocks, more than a short
-        # warm-up gives it: untimed walks over the ring first, then the W warm-up steps.
-        ramp_steps = 0
-        t_ramp = time.perf_counter()
-        while (time.perf_counter() - t_ramp) * 1e3 < args.ramp_ms:
-            run(10 * RING)
-            torch.cuda.synchronize()
-            ramp_steps += 10 * RING
-        run(args.warmup)
-        barrier()
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        t0 = time.perf_counter()
-        ev0.record(stream)
-        run(args.steps)
-        ev1.record(stream)
-        barrier()
-        t1 = time.perf_counter()
-        wall = t1 - t0
-        dev_ms = ev0.elapsed_time(ev1)
-
-    tw = torch.tensor([wall], dtype=torch.float64, device=device)
-    if dist is not None:
-        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
-    wall = float(tw.item())
-
-    # Outside the timed region: what collecting every rank's answers costs per step (the solve
-    # itself never communicates).  all_gather of u_out (A,2) f32 and status (A,) i32 over RCCL.
-    gather_ms = None
-    if dist is not None:
-        try:
-            gu = torch.empty((world * A, 2), dtype=torch.float32, device=device)
-            gs = torch.empty((world * A,), dtype=torch.int32, device=device)
-            reps = 20
-            for i in range(3 + reps):
-                if i == 3:
-                    torch.cuda.synchronize()
-                    tg = time.perf_counter()
-                dist.all_gather_into_tensor(gu, ring[0]["u_out"])
-                dist.all_gather_into_tensor(gs, ring[0]["status"])
-            torch.cuda.synchronize()
-            tg = torch.tensor([(time.perf_counter() - tg) / reps * 1e3], dtype=torch.float64, device=device)
-            dist.all_reduce(tg, op=dist.ReduceOp.MAX)
-            gather_ms = float(tg.item())
-        except Exception as e:  # never at the price of the bench line
-            print("gather timing skipped: %r" % (e,), file=sys.stderr)
-
-    status = torch.stack([b["status"] for b in ring]).cpu().numpy()
-    counts = np.bincount(status.reshape(-1), minlength=3)
-
-    if rank == 0:
-        total_solves = A * args.steps * world
-        value = total_solves / wall
-        kern_ms = dev_ms / args.steps           # device time per step over the timed region
-        abytes = algorithmic_bytes(A, M)
-        achieved = abytes / (kern_ms * 1e-3) / 1e9
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        out = {
-            "metric": "CBF-QP solves/sec (2-input, 16-constraint)",
-            "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": "C4: %d agents x 16 obstacle rows (8 ellipse + 8 collision cone) per GPU, "
-                                   "DBM filter, alpha=1, R=diag(.5,.5), ring of %d distinct batches" % (A, RING),
-                       "agents_per_gpu": A, "rows": M, "lanes_per_qp": args.lanes,
-                       "obs_layout": "planes (M,2,A,4)" if args.planes else "tiles (A/64,M,2,64,4)",
-                       "launch": "eager" if graph is None else "hipGraph of %d launches" % RING,
-                       "clock_ramp_steps_before_warmup": ramp_steps},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel_ms": kern_ms,
-                         "algorithmic_bytes_per_launch": abytes},
-            "status_counts": {"optimal": int(counts[0]), "infeasible": int(counts[1]),
-                              "nonfinite": int(counts[2])},
-        }
-        if gather_ms is not None:
-            out["gather_ms_per_step"] = gather_ms   # not part of value / ms_per_step
-        if world == 1 and not args.no_large and A == AGENTS:
-            try:
-                del ring
-                torch.cuda.empty_cache()
-                out["roofline_large_batch"] = large_batch(flt, device)
-            except Exception as e:  # extra information only
-                out["roofline_large_batch"] = {"error": repr(e)}
-        if world == 1 and not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    args.layout = "planes" if args.planes else "tiles"
+    if args.gpus < 1:
+        ap.error("--gpus must be at least 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launcher(args, sys.argv[1:])
+    return worker(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

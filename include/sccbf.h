@@ -50,7 +50,7 @@
 extern "C" {
 #endif
 
-#define SCCBF_VERSION 100 /* 0.1.0 */
+#define SCCBF_VERSION 200 /* 0.2.0 */
 
 /* obstacle kinds: 0..2 follow Obstacle2DTypes, reference cbf/obstacles.py:51-57 */
 #define SCCBF_OBS_ELLIPSE 0

@@ -5,7 +5,10 @@ There is no CPU fallback: if the HIP library is missing, load() raises.
 import ctypes as C
 import os
 
+from . import _build
 from ._build import LIB
+
+ABI_VERSION = 200   # SCCBF_VERSION of include/sccbf.h this binding was written against
 
 OBS_ELLIPSE, OBS_CONE, OBS_LANE, OBS_RADIAL, OBS_EMPTY = 0, 1, 2, 3, 255
 DYN_DBM, DYN_KBM, DYN_DUM, DYN_SADBM = 0, 1, 2, 3
@@ -62,9 +65,18 @@ def load():
         raise SccbfError(
             "libsccbf.so not found at %s: build it with `python -m sccav_cbf_amd._build` "
             "(hipcc, gfx950). There is no CPU fallback." % LIB)
+    if _build.needs_build():
+        # a library older than its sources may no longer match the argument lists bound below
+        if os.environ.get("SCCBF_NO_REBUILD"):
+            raise SccbfError("libsccbf.so is older than its sources (csrc/, include/sccbf.h): rebuild with "
+                             "`python -m sccav_cbf_amd._build`")
+        _build.build_library()
     L = C.CDLL(LIB)
     vp = C.c_void_p
     L.sccbf_version.restype = C.c_int
+    if L.sccbf_version() != ABI_VERSION:
+        raise SccbfError("libsccbf.so reports ABI version %d, this binding expects %d: rebuild with "
+                         "`python -m sccav_cbf_amd._build`" % (L.sccbf_version(), ABI_VERSION))
     L.sccbf_strerror.restype = C.c_char_p
     L.sccbf_strerror.argtypes = [C.c_int]
     L.sccbf_default_params.restype = None

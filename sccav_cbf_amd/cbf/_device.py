@@ -23,14 +23,25 @@ def _pack(slots):
     return np.ascontiguousarray(slots.reshape(M, 2, 1, 4))
 
 
+_last_partials = (None, None)   # (key, result) of the latest partials() call
+
+
 def partials(s, kinds, slots, zero_tol=1e-3):
-    """h and partials of M obstacle slots for one ego state: (M, 6) = h, hx, hy, hth, hv, ht."""
-    torch = _torch()
-    lib = _lib.load()
+    """h and partials of M obstacle slots for one ego state: (M, 6) = h, hx, hy, hth, hv, ht.
+    The latest result is kept, keyed by the bits of every input: f(), dx(), dy(), dtheta(), dv(),
+    dt() and gradient() on an unchanged obstacle list share one launch and one copy back."""
+    global _last_partials
     kinds = np.ascontiguousarray(kinds, dtype=np.uint8)
     M = kinds.shape[0]
     if M == 0:
         return np.zeros((0, 6))
+    s = np.ascontiguousarray(s, dtype=np.float64)
+    slots = np.ascontiguousarray(slots, dtype=np.float64)
+    key = (s.tobytes(), kinds.tobytes(), slots.tobytes(), float(zero_tol))
+    if _last_partials[0] == key:
+        return _last_partials[1].copy()
+    torch = _torch()
+    lib = _lib.load()
     dev = torch.device("cuda", torch.cuda.current_device())
     st = torch.tensor(np.asarray(s, dtype=np.float64).reshape(1, 4), device=dev)
     ob = torch.tensor(_pack(np.asarray(slots, dtype=np.float64)), device=dev)
@@ -43,8 +54,9 @@ def partials(s, kinds, slots, zero_tol=1e-3):
     _lib.check(lib.sccbf_partials_f64(C.byref(p), 1, M, C.c_void_p(st.data_ptr()),
                                       C.c_void_p(ob.data_ptr()), C.c_void_p(ty.data_ptr()),
                                       C.c_void_p(out.data_ptr()), C.c_void_p(stream)))
-    o = out.cpu().numpy().reshape(M, 8)
-    return o[:, :6]
+    o = out.cpu().numpy().reshape(M, 8)[:, :6].copy()
+    _last_partials = (key, o)
+    return o.copy()
 
 
 def solve(params, s, u_ref, kinds, slots):

@@ -13,6 +13,7 @@ length-2 float arrays (the reference returns a 2x1 cvxopt matrix, indexed u[0], 
 """
 import ctypes as C
 import time
+import warnings
 
 import numpy as np
 
@@ -23,6 +24,19 @@ from .obstacles import Obstacle2DTypes, ObstacleList2D
 from .utils import ZERO_TOL
 
 _STATUS = {0: "optimal", 1: "infeasible", 2: "non-finite input"}
+
+
+class CBFStatusWarning(RuntimeWarning):
+    """The filter could not produce a safe input and handed back the nominal one."""
+
+
+def _note_status(flt, status):
+    """Keep the device's verdict on the filter object and say so when the answer is the unfiltered
+    nominal input (the reference never looks at cvxopt's status, cbf/cbf.py:213-220)."""
+    flt.last_status = int(status)
+    if status != 0:
+        warnings.warn("CBF-QP %s: solve_cbf returns the nominal input unchanged (last_status = %d)"
+                      % (_STATUS.get(status, "unknown"), status), CBFStatusWarning, stacklevel=3)
 
 
 class _FilterBase:
@@ -39,6 +53,7 @@ class _FilterBase:
         self._lf = 1.45
         self._L = 2.9
         self.s = np.zeros(4)
+        self.last_status = 0   # 0 optimal, 1 infeasible, 2 non-finite input: of the latest solve_cbf
 
     def set_alpha(self, alpha=1.0):
         self._alpha = alpha
@@ -68,6 +83,7 @@ class _FilterBase:
         u_ref = np.asarray(u_ref, dtype=np.float64).reshape(-1)
         kinds, slots = self.obstacle_list2d.slots()
         u, status, rows = _device.solve(self._params(), self.s, u_ref, kinds, slots)
+        _note_status(self, status)
         info = {"x": u.copy(), "status": _STATUS.get(status, "unknown"), "status_code": status,
                 "rows": rows}
         return info, u
@@ -169,6 +185,7 @@ class SADBM_CBF_2DS(DBM_CBF_2DS):
         u, status, rows, slip = _device.solve_sa(self._params(), self._dt, self.s, [self._beta, last], u_ref,
                                                  kinds, slots)
         self._beta, self.beta_ref_last = float(slip[0]), float(slip[1])
+        _note_status(self, status)
         self.beta_ref_dot = (self.beta_ref_last - last) / self._dt
         # every collision cone follows the filter's slip angle (cbf.py:424-427)
         for obstacle in self.obstacle_list2d.values():

@@ -114,16 +114,60 @@ class ClosedLoop:
         self.traj, self.state, self.obs, self.obs_type = traj, state, obs, obs_type
         self.max_steer, self.dt = float(max_steer), float(dt)
         A, dev, ty = state.shape[0], state.device, state.dtype
-        self.target_idx = torch.zeros((A,), dtype=torch.int32, device=dev)
-        self.pid_state = torch.zeros((A, 2), dtype=ty, device=dev) if use_pid_state else None
         if (nominal is None) != (traj is None):
             raise ValueError("give both a nominal controller and a course, or neither")
+        self._check_inputs()
+        self.target_idx = torch.zeros((A,), dtype=torch.int32, device=dev)
+        self.pid_state = torch.zeros((A, 2), dtype=ty, device=dev) if use_pid_state else None
         self.u_ref = torch.zeros((A, 2), dtype=ty, device=dev)
         self.u = torch.empty((A, 2), dtype=ty, device=dev)
         self.status = torch.empty((A,), dtype=torch.int32, device=dev)
         self.beta = torch.empty((A,), dtype=ty, device=dev)
         # steer-rate model (SADBM_CBF_2DS): the filter integrates its own slip angle; the cones follow it
         self.slip = torch.zeros((A, 2), dtype=ty, device=dev) if cbf.params.dynamics == _lib.DYN_SADBM else None
+
+    def _check_inputs(self):
+        """Shapes, dtypes, device and contiguity of every tensor the kernels index: a tensor built
+        for another batch size, precision or layout must raise here, never reach a launch.
+        Returns (M, layout flags)."""
+        state = self.state
+        if not torch.is_tensor(state) or state.dim() != 2:
+            raise ValueError("state: expected a (A, 4) tensor")
+        A, dev, ty = state.shape[0], state.device, state.dtype
+        if ty not in (torch.float32, torch.float64):
+            raise ValueError("state must be float32 or float64")
+        _check("state", state, (A, 4), ty, dev)
+        obs, flags = self.obs, 0
+        if not torch.is_tensor(obs) or obs.dim() not in (3, 4, 5):
+            raise ValueError("obs: expected planes (M,2,A,4), tiles (ceil(A/64),M,2,64,4) or a shared table (M,2,4)")
+        if obs.dim() == 5:
+            M = obs.shape[1]
+            flags |= _lib.FLAG_OBS_TILED
+            _check("obs", obs, ((A + 63) // 64, M, 2, 64, 4), ty, dev)
+        elif obs.dim() == 4:
+            M = obs.shape[0]
+            _check("obs", obs, (M, 2, A, 4), ty, dev)
+        else:
+            M = obs.shape[0]
+            flags |= _lib.FLAG_OBS_SHARED
+            _check("obs", obs, (M, 2, 4), ty, dev)
+        if not torch.is_tensor(self.obs_type) or self.obs_type.dim() not in (1, 2):
+            raise ValueError("obs_type: expected uint8 (M,) or (M, A)")
+        if self.obs_type.dim() == 2:
+            flags |= _lib.FLAG_TYPE_PER_AGENT
+            _check("obs_type", self.obs_type, (M, A), torch.uint8, dev)
+        else:
+            _check("obs_type", self.obs_type, (M,), torch.uint8, dev)
+        if self.traj is not None:
+            if not torch.is_tensor(self.traj) or self.traj.dim() != 2 or self.traj.shape[0] < 1:
+                raise ValueError("traj: expected a (N, 4) tensor with at least one way-point")
+            _check("traj", self.traj, (self.traj.shape[0], 4), ty, dev)
+        for name, t, shape, dt in (("target_idx", getattr(self, "target_idx", None), (A,), torch.int32),
+                                   ("pid_state", getattr(self, "pid_state", None), (A, 2), ty),
+                                   ("slip", getattr(self, "slip", None), (A, 2), ty)):
+            if t is not None:
+                _check(name, t, shape, dt, dev)
+        return M, flags
 
     def rollout(self, ticks, motion="static", trace=False, seek_gain=0.2, seek_v_min=3.0, out=None):
         """`ticks` ticks in ONE launch (sccbf_rollout_*): state, target_idx and pid_state advance in
@@ -135,18 +179,15 @@ class ClosedLoop:
         captured in a hipGraph."""
         A, dev, ty = self.state.shape[0], self.state.device, self.state.dtype
         obs = self.obs
-        flags = self.cbf.params.flags & ~(_lib.FLAG_OBS_SHARED | _lib.FLAG_OBS_TILED | _lib.FLAG_TYPE_PER_AGENT)
-        if obs.dim() == 5:
-            flags |= _lib.FLAG_OBS_TILED
-            M = obs.shape[1]
-        elif obs.dim() == 4:
-            M = obs.shape[0]
-        else:
+        M, flags = self._check_inputs()
+        if flags & _lib.FLAG_OBS_SHARED:
             raise ValueError("rollout needs per-agent obstacle slots (planes or tiles)")
-        if self.obs_type.dim() == 2:
-            flags |= _lib.FLAG_TYPE_PER_AGENT
         if self.cbf.slip_io:
             raise ValueError("rollout works in the caller's coordinates (a, delta): slip_io must be off")
+        if int(ticks) < 0:
+            raise ValueError("ticks must not be negative")
+        if not self.state.is_cuda:
+            raise _lib.SccbfError("ClosedLoop.rollout needs tensors on the GPU (no CPU fallback)")
         N = 0 if self.traj is None else self.traj.shape[0]
         rp = _lib.RolloutParams()
         lib = _lib.load()
@@ -168,11 +209,12 @@ class ClosedLoop:
             _check("out['n_infeasible']", out["n_infeasible"], (A,), torch.int32, dev)
             if "trace" in out:
                 _check("out['trace']", out["trace"], (int(ticks), A, 4), ty, dev)
-        self.cbf.params.flags = flags
+        params = _lib.Params.from_buffer_copy(self.cbf.params)   # the filter object keeps its own flags
+        params.flags = flags
         fn = lib.sccbf_rollout_f32 if ty == torch.float32 else lib.sccbf_rollout_f64
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
-            rc = fn(C.byref(self.cbf.params), C.byref(nominal_params), C.byref(rp), A, M, N,
+            rc = fn(C.byref(params), C.byref(nominal_params), C.byref(rp), A, M, N,
                     _ptr(self.state), _ptr(self.traj), _ptr(self.target_idx), _ptr(self.pid_state), _ptr(obs),
                     _ptr(self.obs_type), _ptr(out["h_min"]), _ptr(out["n_active"]), _ptr(out["n_infeasible"]),
                     _ptr(out.get("trace")), C.c_void_p(stream))
@@ -180,6 +222,12 @@ class ClosedLoop:
         return out
 
     def tick(self):
+        dyn = self.cbf.params.dynamics
+        if dyn not in (_lib.DYN_DBM, _lib.DYN_SADBM) or (dyn == _lib.DYN_DBM and self.cbf.slip_io):
+            # the vehicle step below is update_com of the DBM drivers and takes (a, delta)
+            raise ValueError("ClosedLoop.tick steps the vehicle with (a, delta): use a DBM filter without "
+                             "slip_io or the steer-rate filter (KBM / DUM answers are (v, delta) / (a, omega))")
+        self._check_inputs()
         if self.nominal is not None:
             self.nominal.control(self.state, self.traj, self.target_idx, self.pid_state, u_ref=self.u_ref)
         if self.slip is not None:

@@ -32,7 +32,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_version_and_strerror(lib):
-    assert lib.sccbf_version() == 100
+    assert lib.sccbf_version() == _lib.ABI_VERSION
     assert lib.sccbf_strerror(0) == b"ok"
     for code in range(-6, 0):
         assert len(lib.sccbf_strerror(code)) > 3

@@ -159,3 +159,77 @@ def test_controllers():
     assert abs(u2 - (2.0 * 1 + 0.1 * 0.3 + 0.5 * (-10))) < 1e-12
     assert abs(normalize_angle(3 * np.pi) - np.pi) < 1e-12 and abs(vec_norm([3, 4]) - 5) < 1e-12
     assert abs(normalize_angle(1e17)) <= np.pi and normalize_angle(float("inf")) == float("inf")   # and they return
+
+
+def _closed_loop_parts(A=8, M=3, N=5, dtype=None):
+    import torch
+    dtype = dtype or torch.float32
+    return dict(traj=torch.zeros((N, 4), dtype=dtype), state=torch.zeros((A, 4), dtype=dtype),
+                obs=torch.zeros((M, 2, A, 4), dtype=dtype), obs_type=torch.zeros((M,), dtype=torch.uint8))
+
+
+def test_closed_loop_rejects_mismatched_tensors_before_any_launch():
+    """Tensors built for another batch size, precision or layout must raise ValueError on the host:
+    the C ABI checks pointers only, the kernels index by the shapes they are told."""
+    import torch
+    from sccav_cbf_amd import _lib
+    from sccav_cbf_amd.batched import BatchedCBF
+    from sccav_cbf_amd.nominal import BatchedNominal, ClosedLoop
+    flt, nom = BatchedCBF(), BatchedNominal()
+    ok = _closed_loop_parts()
+    loop = ClosedLoop(flt, nom, **ok)                  # consistent CPU tensors: accepted by the checks ...
+    with pytest.raises(_lib.SccbfError):               # ... and refused only for want of a GPU
+        loop.rollout(3)
+    bad = [("obs", torch.zeros((3, 2, 8, 4), dtype=torch.float64)),           # precision of another batch
+           ("obs", torch.zeros((3, 2, 9, 4))),                               # another A
+           ("obs", torch.zeros((1, 3, 2, 32, 4))),                           # tiles of the wrong size
+           ("obs", torch.zeros((3, 2, 4, 8)).transpose(2, 3)),               # a view, not contiguous
+           ("obs_type", torch.zeros((3, 7), dtype=torch.uint8)),             # per-agent kinds of another A
+           ("obs_type", torch.zeros((3,), dtype=torch.int32)),
+           ("traj", torch.zeros((5, 3))),
+           ("traj", torch.zeros((5, 4), dtype=torch.float64)),
+           ("state", torch.zeros((8, 3)))]
+    for name, t in bad:
+        with pytest.raises(ValueError):
+            ClosedLoop(flt, nom, **dict(ok, **{name: t}))
+    # tensors swapped in after construction are checked again by rollout() and tick()
+    loop.obs = torch.zeros((3, 2, 9, 4))
+    with pytest.raises(ValueError):
+        loop.rollout(3)
+    with pytest.raises(ValueError):
+        loop.tick()
+    loop.obs = ok["obs"]
+    loop.target_idx = torch.zeros((7,), dtype=torch.int32)
+    with pytest.raises(ValueError):
+        loop.rollout(3)
+    with pytest.raises(ValueError):
+        ClosedLoop(flt, None, **ok)                    # a course without a controller
+
+
+def test_closed_loop_tick_refuses_models_the_vehicle_step_does_not_fit():
+    from sccav_cbf_amd.batched import BatchedCBF
+    from sccav_cbf_amd.nominal import BatchedNominal, ClosedLoop
+    for kw in (dict(dynamics="kbm"), dict(dynamics="dum"), dict(dynamics="dbm", slip_io=True)):
+        loop = ClosedLoop(BatchedCBF(**kw), BatchedNominal(), **_closed_loop_parts())
+        with pytest.raises(ValueError, match="a, delta"):
+            loop.tick()
+
+
+def test_rollout_leaves_the_filter_flags_alone():
+    from sccav_cbf_amd import _lib
+    from sccav_cbf_amd.batched import BatchedCBF
+    from sccav_cbf_amd.nominal import BatchedNominal, ClosedLoop
+    flt = BatchedCBF()
+    flt.params.flags = _lib.FLAG_TYPE_PER_AGENT
+    loop = ClosedLoop(flt, BatchedNominal(), **_closed_loop_parts())
+    with pytest.raises(_lib.SccbfError):
+        loop.rollout(2)
+    assert flt.params.flags == _lib.FLAG_TYPE_PER_AGENT
+
+
+def test_library_version_matches_the_binding():
+    from sccav_cbf_amd import _lib
+    import re, os
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "sccbf.h")).read()
+    assert int(re.search(r"#define SCCBF_VERSION (\d+)", hdr).group(1)) == _lib.ABI_VERSION
+    assert _lib.load().sccbf_version() == _lib.ABI_VERSION
