@@ -44,11 +44,19 @@ def algorithmic_bytes(A, M, w=4):
     return A * (w * (4 + 2 + 8 * M + 2) + 4)
 
 
-def make_ring(rank, device, n=RING, agents=AGENTS, layout="tiles"):
+def c4_batch(agents, seed, slots):
+    """One C4 batch: 8 ellipse + 8 collision-cone slots per agent, as the reference's objects hold them
+    ("written") or with the per-obstacle constants evaluated ("prepared", kinds 4 and 5: same obstacles,
+    same 8 scalars per slot, same rows)."""
+    w = scenarios.config4(A=agents, seed=seed)
+    return scenarios.prepared(w) if slots == "prepared" else w
+
+
+def make_ring(rank, device, n=RING, agents=AGENTS, layout="tiles", slots="prepared"):
     from sccav_cbf_amd.batched import planes_to_tiled
     ring = []
     for b in range(n):
-        w = scenarios.config4(A=agents, seed=1234 + 4 + 1000 * rank + b)
+        w = c4_batch(agents, 1234 + 4 + 1000 * rank + b, slots)
         t = dict(state=torch.from_numpy(w["state"]).float().to(device),
                  u_ref=torch.from_numpy(w["u_ref"]).float().to(device),
                  obs=torch.from_numpy(w["obs"]).float().to(device),   # (M,2,A,4) planes
@@ -152,12 +160,12 @@ def _time_graph(walk, stream, n_per_walk, reps):
     return e0.elapsed_time(e1) / (reps * n_per_walk)   # ms per launch
 
 
-def large_batch(flt, device, layout, agents=1 << 20, n=3, reps=60):
+def large_batch(flt, device, layout, slots, agents=1 << 20, n=3, reps=60):
     """The same kernel on 2^20 agents per launch (not part of `value`): at that size a launch is
     no longer dominated by its start-up and tail.  The ring re-uses one C4 batch rotated by whole
     tiles: 3 x 575 MB, more than twice the Infinity Cache."""
     from sccav_cbf_amd.batched import planes_to_tiled
-    w = scenarios.config4(A=agents, seed=99)
+    w = c4_batch(agents, 99, slots)
     ring = []
     for b in range(n):
         sh = 64 * 1237 * (b + 1)
@@ -330,8 +338,10 @@ def worker(args):
         flt = None
     else:
         from sccav_cbf_amd.batched import BatchedCBF
-        flt = BatchedCBF(alpha=1.0, lr=1.45, lf=1.45, R=np.diag([0.5, 0.5]), lanes_per_qp=args.lanes)
-        ring = make_ring(rank, device, agents=A, layout=args.layout)
+        # every step reads a batch that is not touched again for RING - 1 steps: say so
+        flt = BatchedCBF(alpha=1.0, lr=1.45, lf=1.45, R=np.diag([0.5, 0.5]), lanes_per_qp=args.lanes,
+                         streamed_obs=not args.no_stream_hint)
+        ring = make_ring(rank, device, agents=A, layout=args.layout, slots=args.slots)
 
         def step(i):
             b = ring[i % RING]
@@ -451,6 +461,8 @@ def worker(args):
                                    "DBM filter, alpha=1, R=diag(.5,.5), ring of %d distinct batches" % (A, RING),
                        "agents_per_gpu": A, "rows": M, "lanes_per_qp": args.lanes,
                        "obs_layout": layout_name,
+                       "obs_slots": "prepared (kinds 4, 5: 1/a^2, 1/b^2, cos, sin and the cone's obstacle velocity "
+                                    "stored in the slot)" if args.slots == "prepared" else "as written (kinds 0, 1)",
                        "launch": "eager" if graph is None else "hipGraph of %d launches" % RING,
                        "clock_ramp_steps_before_warmup": ramp_steps},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -477,7 +489,7 @@ def worker(args):
             try:
                 del ring
                 torch.cuda.empty_cache()
-                out["roofline_large_batch"] = large_batch(flt, device, args.layout)
+                out["roofline_large_batch"] = large_batch(flt, device, args.layout, args.slots)
             except Exception as e:  # extra information only
                 out["roofline_large_batch"] = {"error": repr(e)}
         if world == 1 and not stub and not args.no_fp64 and A == AGENTS:
@@ -504,6 +516,11 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
     ap.add_argument("--planes", action="store_true", help="obstacles as (M,2,A,4) planes instead of 64-agent tiles")
+    ap.add_argument("--slots", choices=("prepared", "written"), default="prepared",
+                    help="ellipse / cone slots with their per-obstacle constants evaluated (default) or as the "
+                         "reference's objects hold them; 8 scalars per slot either way")
+    ap.add_argument("--no-stream-hint", action="store_true",
+                    help="do not tell the library that each step's obstacle slots are read once (SCCBF_FLAG_OBS_STREAMED)")
     ap.add_argument("--no-large", action="store_true", help="skip the extra 1M-agent measurement (N=1 only)")
     ap.add_argument("--no-fp64", action="store_true", help="skip the fp64 lines (N=1 only)")
     ap.add_argument("--ramp-ms", type=float, default=60.0,

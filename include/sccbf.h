@@ -40,6 +40,11 @@
  *   SCCBF_OBS_LANE     c0, c1, c2, c3, buffer, -, -, -       y = c0+c1 x+c2 x^2+c3 x^3
  *   SCCBF_OBS_RADIAL   cx, cy, a, b, cdot_x, cdot_y, kv, -
  *   SCCBF_OBS_EMPTY    ignored (row 0.u >= -1, always satisfied)
+ * Prepared kinds: the same obstacles with everything that does not depend on the agent already
+ * evaluated by whoever writes the slot (sccbf_prepare_obs_*, sccbf_ingest_bbox_*), so that the
+ * filter does no sine, cosine or reciprocal per slot and tick; same 8 scalars, same rows
+ *   SCCBF_OBS_ELLIPSE_PREP  cx, cy, 1/a^2, 1/b^2, cos(theta_o), sin(theta_o), vx, vy
+ *   SCCBF_OBS_CONE_PREP     cx, cy, v_o cos(theta_o + beta), v_o sin(theta_o + beta), a, beta, -, -
  */
 #ifndef SCCBF_H_
 #define SCCBF_H_
@@ -57,6 +62,8 @@ extern "C" {
 #define SCCBF_OBS_CONE 1
 #define SCCBF_OBS_LANE 2
 #define SCCBF_OBS_RADIAL 3 /* test_scripts/radial_dynamic_obstacles.py:391-411 */
+#define SCCBF_OBS_ELLIPSE_PREP 4 /* Ellipse2D, reference cbf/obstacles.py:183-236, 310-317, constants evaluated */
+#define SCCBF_OBS_CONE_PREP 5    /* CollisionCone2D, cbf/obstacles.py:401-502, obstacle velocity resolved */
 #define SCCBF_OBS_EMPTY 255
 
 /* vehicle model */
@@ -89,6 +96,11 @@ extern "C" {
                                           agent's slip state instead of its own o[5], which is what
                                           the reference's cones hold after SADBM's first solve
                                           (cbf.py:424-427) */
+
+#define SCCBF_FLAG_OBS_STREAMED 32u   /* the obstacle slots of this call will not be read again soon (every
+                                          tick brings new ones): they are loaded with the non-temporal
+                                          hint and leave the caches to the other arrays.  Without it the
+                                          library decides by size.  A hint: results do not depend on it */
 
 /* error codes */
 #define SCCBF_OK 0
@@ -351,6 +363,7 @@ int sccbf_rollout_f64(const sccbf_params* p, const sccbf_nominal_params* np,
  *                            b = extent y + buffer, theta_o = yaw, at rest
  *         SCCBF_OBS_CONE     CollisionCone2D.from_bounding_box (534-543): a = hypot(extent x,
  *                            extent y) + buffer, theta_o = 0, v_o = speed
+ *         SCCBF_OBS_ELLIPSE_PREP, SCCBF_OBS_CONE_PREP   the same two in their prepared forms
  *         anything else      an all-zero slot (pair it with SCCBF_OBS_EMPTY)
  *   obs   out, T[M][2][A][4], or tiles with SCCBF_FLAG_OBS_TILED in flags
  */
@@ -358,6 +371,24 @@ int sccbf_ingest_bbox_f32(int64_t A, int32_t M, const float* bbox, const uint8_t
                           double buffer, uint32_t flags, float* obs, void* stream);
 int sccbf_ingest_bbox_f64(int64_t A, int32_t M, const double* bbox, const uint8_t* kind,
                           double buffer, uint32_t flags, double* obs, void* stream);
+
+/*
+ * As-written ellipse and cone slots -> their prepared forms (SCCBF_OBS_ELLIPSE_PREP,
+ * SCCBF_OBS_CONE_PREP), in place: the values that reference cbf/obstacles.py recomputes from the
+ * obstacle alone in every partial of every tick (np.cos / np.sin of the ellipse angle, 1/a^2,
+ * 1/b^2: 183-236; the cone's obstacle velocity v_o (cos, sin)(theta_o + beta): 489-490) are
+ * evaluated once, in double precision, and obs_type is rewritten to the prepared kinds.  Other
+ * kinds and already prepared slots are left as they are.  Call it when obstacles change, not per
+ * tick; sccbf_ingest_bbox_* writes prepared slots directly when `kind` names them.
+ *   obs       in/out, layout by flags: planes, SCCBF_FLAG_OBS_TILED or SCCBF_FLAG_OBS_SHARED
+ *   obs_type  in/out, u8[M] or u8[M][A] with SCCBF_FLAG_TYPE_PER_AGENT
+ * A prepared cone keeps the beta it was prepared with (SCCBF_FLAG_CONE_BETA_STATE does not
+ * reach it).
+ */
+int sccbf_prepare_obs_f32(int64_t A, int32_t M, float* obs, uint8_t* obs_type, uint32_t flags,
+                          void* stream);
+int sccbf_prepare_obs_f64(int64_t A, int32_t M, double* obs, uint8_t* obs_type, uint32_t flags,
+                          void* stream);
 
 /*
  * Lane points -> lane slot m of every agent: PolyLane.fit_polynomial_curve, reference

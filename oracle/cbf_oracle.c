@@ -33,6 +33,8 @@
 #define ORC_OBS_CONE 1
 #define ORC_OBS_LANE 2
 #define ORC_OBS_RADIAL 3
+#define ORC_OBS_ELLIPSE_PREP 4
+#define ORC_OBS_CONE_PREP 5
 #define ORC_OBS_EMPTY 255
 
 #define ORC_DYN_DBM 0
@@ -86,6 +88,23 @@ static void orc_ellipse(const double s[4], const double o[8], orc_partials* r)
     r->ht = -2.0 * ((xd / (a * a)) * o[5] + (yd / (b * b)) * o[6]);
 }
 
+/* The same Ellipse2D formulas (cbf/obstacles.py:183-194, 210-236, 304-317) on a slot that
+ * already holds the per-obstacle constants: o = cx, cy, 1/a^2, 1/b^2, cos(theta_o),
+ * sin(theta_o), vx, vy. */
+static void orc_ellipse_prep(const double s[4], const double o[8], orc_partials* r)
+{
+    double xd = s[0] - o[0], yd = s[1] - o[1];
+    double ia2 = o[2], ib2 = o[3], ct = o[4], st = o[5];
+    double p = xd * ct + yd * st;
+    double q = -xd * st + yd * ct;
+    r->h = p * p * ia2 + q * q * ib2 - 1.0;
+    r->hx = (2.0 * ct * ia2) * p + (-2.0 * st * ib2) * q;
+    r->hy = (2.0 * st * ia2) * p + (2.0 * ct * ib2) * q;
+    r->hth = 0.0;
+    r->hv = 0.0;
+    r->ht = -2.0 * ((xd * ia2) * o[6] + (yd * ib2) * o[7]);
+}
+
 /* Time-varying ellipse with a speed-dependent margin,
  * test_scripts/radial_dynamic_obstacles.py:391-405.
  * o = cx, cy, a, b, cdot_x, cdot_y, kv. */
@@ -103,12 +122,11 @@ static void orc_radial(const double s[4], const double o[8], orc_partials* r)
 
 /* CollisionCone2D.update/evaluate/dx/dy/dv/dtheta/dt,
  * cbf/obstacles.py:468-502, 401-458.  o = cx, cy, theta_o, v_o, a, beta. */
-static void orc_cone(const double s[4], const double o[8], double eps, orc_partials* r)
+static void orc_cone_core(const double s[4], double cx, double cy, double ovx, double ovy, double a,
+                          double beta, double eps, orc_partials* r)
 {
-    double xd = s[0] - o[0], yd = s[1] - o[1];
-    double beta = o[5], a = o[4];
+    double xd = s[0] - cx, yd = s[1] - cy;
     double svx = s[3] * cos(s[2]), svy = s[3] * sin(s[2]);
-    double ovx = o[3] * cos(o[2] + beta), ovy = o[3] * sin(o[2] + beta);
     double dvx = svx - ovx, dvy = svy - ovy;
     double dist = sqrt(xd * xd + yd * yd);
     double vn = sqrt(dvx * dvx + dvy * dvy);
@@ -122,6 +140,19 @@ static void orc_cone(const double s[4], const double o[8], double eps, orc_parti
     r->hv = (xd * c + yd * sn) + (dvx * c + dvy * sn) * cb / (vn + eps);
     r->hth = (-xd * svy + yd * svx) + (-dvx * svy + dvy * svx) * cb / (vn + eps);
     r->ht = (-dvx * ovx - dvy * ovy) - vn * (xd * ovx + yd * ovy) / (cb + eps);
+}
+
+static void orc_cone(const double s[4], const double o[8], double eps, orc_partials* r)
+{
+    double beta = o[5];
+    orc_cone_core(s, o[0], o[1], o[3] * cos(o[2] + beta), o[3] * sin(o[2] + beta), o[4], beta, eps, r);
+}
+
+/* The same collision cone on a slot that holds the obstacle's velocity already resolved
+ * (cbf/obstacles.py:489-490): o = cx, cy, v_o cos(theta_o + beta), v_o sin(theta_o + beta), a, beta. */
+static void orc_cone_prep(const double s[4], const double o[8], double eps, orc_partials* r)
+{
+    orc_cone_core(s, o[0], o[1], o[2], o[3], o[4], o[5], eps, r);
 }
 
 static void orc_poly3(const double c[4], double x, double* f, double* df, double* ddf)
@@ -193,6 +224,8 @@ int orc_barrier(int type, const double s[4], const double o[8], double zero_tol,
     case ORC_OBS_CONE: orc_cone(s, o, zero_tol, r); return 1;
     case ORC_OBS_LANE: orc_lane(s, o, zero_tol, r); return 1;
     case ORC_OBS_RADIAL: orc_radial(s, o, r); return 1;
+    case ORC_OBS_ELLIPSE_PREP: orc_ellipse_prep(s, o, r); return 1;
+    case ORC_OBS_CONE_PREP: orc_cone_prep(s, o, zero_tol, r); return 1;
     default:
         memset(r, 0, sizeof(*r));
         r->h = 1.0;
@@ -526,7 +559,7 @@ int orc_solve_sa_batch(const orc_params* p, double dt, int64_t A, int32_t M, con
             orc_partials d;
             double* row = rows + 3 * m;
             if (orc_barrier(type, s, o, p->zero_tol, &d)) {
-                orc_row_sa(p, s, beta, &d, type == ORC_OBS_CONE ? d.hth : 0.0, row);
+                orc_row_sa(p, s, beta, &d, (type == ORC_OBS_CONE || type == ORC_OBS_CONE_PREP) ? d.hth : 0.0, row);
                 if (!(orc_finite(row[0]) && orc_finite(row[1]) && orc_finite(row[2]))) bad = 1;
             } else {
                 row[0] = 0.0; row[1] = 0.0; row[2] = -1.0;

@@ -14,6 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "liboracle.so")
 
 OBS_ELLIPSE, OBS_CONE, OBS_LANE, OBS_RADIAL, OBS_EMPTY = 0, 1, 2, 3, 255
+OBS_ELLIPSE_PREP, OBS_CONE_PREP = 4, 5
 DYN_DBM, DYN_KBM, DYN_DUM, DYN_SADBM = 0, 1, 2, 3
 FLAG_OBS_SHARED, FLAG_TYPE_PER_AGENT, FLAG_SLIP_IO = 1, 2, 4
 FLAG_CONE_BETA_STATE = 16
@@ -253,10 +254,21 @@ def seeker_step(obs, obs_type, ego_xy, dt, k=0.2, v_min=3.0):
                 obs[m, 1, :, 0], obs[m, 1, :, 1] = vx, vy
             cx += vx * dt
             cy += vy * dt
+        elif kind == OBS_ELLIPSE_PREP:   # the same ellipse, slot = cx, cy, 1/a^2, 1/b^2 | cos, sin, vx, vy
+            cx, cy = obs[m, 0, :, 0], obs[m, 0, :, 1]
+            yaw = np.arctan2(ego_xy[:, 1] - cy, ego_xy[:, 0] - cx)
+            v = np.maximum(k * np.hypot(ego_xy[:, 0] - cx, ego_xy[:, 1] - cy), v_min)
+            vx, vy = v * np.cos(yaw), v * np.sin(yaw)
+            obs[m, 1, :, 0], obs[m, 1, :, 1], obs[m, 1, :, 2], obs[m, 1, :, 3] = np.cos(yaw), np.sin(yaw), vx, vy
+            cx += vx * dt
+            cy += vy * dt
         elif kind == OBS_CONE:
             ang = obs[m, 0, :, 2] + obs[m, 1, :, 1]
             obs[m, 0, :, 0] += obs[m, 0, :, 3] * np.cos(ang) * dt
             obs[m, 0, :, 1] += obs[m, 0, :, 3] * np.sin(ang) * dt
+        elif kind == OBS_CONE_PREP:
+            obs[m, 0, :, 0] += obs[m, 0, :, 2] * dt
+            obs[m, 0, :, 1] += obs[m, 0, :, 3] * dt
 
 
 def ingest_bbox(bbox, kind, buffer=0.5):
@@ -272,11 +284,13 @@ def ingest_bbox(bbox, kind, buffer=0.5):
     x, y, ex, ey, yaw, sp = (bbox[:, 0, :, 0], bbox[:, 0, :, 1], bbox[:, 0, :, 2], bbox[:, 0, :, 3],
                              bbox[:, 1, :, 0], bbox[:, 1, :, 1])
     e, c = kind == OBS_ELLIPSE, kind == OBS_CONE
-    obs[:, 0, :, 0] = np.where(e | c, x, 0.0)
-    obs[:, 0, :, 1] = np.where(e | c, y, 0.0)
-    obs[:, 0, :, 2] = np.where(e, ex + buffer, 0.0)
-    obs[:, 0, :, 3] = np.where(e, ey + buffer, np.where(c, sp, 0.0))
-    obs[:, 1, :, 0] = np.where(e, yaw, np.where(c, np.hypot(ex, ey) + buffer, 0.0))
+    ep, cp = kind == OBS_ELLIPSE_PREP, kind == OBS_CONE_PREP   # the same two, per-obstacle constants evaluated
+    obs[:, 0, :, 0] = np.where(e | c | ep | cp, x, 0.0)
+    obs[:, 0, :, 1] = np.where(e | c | ep | cp, y, 0.0)
+    obs[:, 0, :, 2] = np.where(e, ex + buffer, np.where(ep, 1.0 / (ex + buffer) ** 2, np.where(cp, sp, 0.0)))
+    obs[:, 0, :, 3] = np.where(e, ey + buffer, np.where(c, sp, np.where(ep, 1.0 / (ey + buffer) ** 2, 0.0)))
+    obs[:, 1, :, 0] = np.where(e, yaw, np.where(c | cp, np.hypot(ex, ey) + buffer, np.where(ep, np.cos(yaw), 0.0)))
+    obs[:, 1, :, 1] = np.where(ep, np.sin(yaw), 0.0)
     return obs
 
 

@@ -12,7 +12,7 @@ LIB_DIR = os.path.join(_PKG, "lib")
 LIB = os.path.join(LIB_DIR, "libsccbf.so")
 
 HIPCC_FLAGS = [
-    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",   # -shared: link step only
     # packed-fp32 forms have produced sporadic wrong results on this hardware pool
     "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops",
     # leading scalar kernel arguments arrive in SGPRs at wave launch instead of through s_load
@@ -34,12 +34,27 @@ def build_library(force=False, verbose=False):
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [hipcc] + HIPCC_FLAGS + ["-I" + os.path.join(_ROOT, "include"), "-o", LIB, SRC]
+    # the one source file, once per precision, side by side; then one link
+    cflags = [f for f in HIPCC_FLAGS if f != "-shared"] + ["-I" + os.path.join(_ROOT, "include"), "-c"]
+    objs, procs = [], []
+    for tag in ("F32", "F64"):
+        obj = os.path.join(LIB_DIR, "sccbf_%s.o" % tag.lower())
+        cmd = [hipcc] + cflags + ["-DSCCBF_ONLY_" + tag, "-o", obj, SRC]
+        if verbose:
+            print(" ".join(cmd))
+        objs.append(obj)
+        procs.append(subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    logs = [p.communicate()[0] for p in procs]
+    if any(p.returncode != 0 for p in procs):
+        raise RuntimeError("hipcc failed:\n" + "\n".join(logs))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
         print(" ".join(cmd))
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if res.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + res.stdout)
+        raise RuntimeError("hipcc link failed:\n" + res.stdout)
+    for obj in objs:
+        os.remove(obj)
     return LIB
 
 

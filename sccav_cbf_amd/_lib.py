@@ -11,10 +11,12 @@ from ._build import LIB
 ABI_VERSION = 200   # SCCBF_VERSION of include/sccbf.h this binding was written against
 
 OBS_ELLIPSE, OBS_CONE, OBS_LANE, OBS_RADIAL, OBS_EMPTY = 0, 1, 2, 3, 255
+OBS_ELLIPSE_PREP, OBS_CONE_PREP = 4, 5   # the same obstacles, per-obstacle constants already evaluated
 DYN_DBM, DYN_KBM, DYN_DUM, DYN_SADBM = 0, 1, 2, 3
 STATUS_OPTIMAL, STATUS_INFEASIBLE, STATUS_NONFINITE = 0, 1, 2
 FLAG_OBS_SHARED, FLAG_TYPE_PER_AGENT, FLAG_SLIP_IO, FLAG_OBS_TILED = 1, 2, 4, 8
 FLAG_CONE_BETA_STATE = 16
+FLAG_OBS_STREAMED = 32
 MAX_ROWS = 1024
 ERR_ARG, ERR_ROWS, ERR_WEIGHT, ERR_LAUNCH, ERR_VARIANT, ERR_NO_DEVICE = -1, -2, -3, -4, -5, -6
 
@@ -24,7 +26,8 @@ EXPORTS = ("sccbf_version", "sccbf_strerror", "sccbf_default_params", "sccbf_sol
            "sccbf_nominal_f64", "sccbf_vehicle_step_f32", "sccbf_vehicle_step_f64",
            "sccbf_default_rollout_params", "sccbf_rollout_f32", "sccbf_rollout_f64",
            "sccbf_solve_sa_f32", "sccbf_solve_sa_f64", "sccbf_ingest_bbox_f32", "sccbf_ingest_bbox_f64",
-           "sccbf_lane_fit_f32", "sccbf_lane_fit_f64", "sccbf_solve_step_f32", "sccbf_solve_step_f64")
+           "sccbf_lane_fit_f32", "sccbf_lane_fit_f64", "sccbf_solve_step_f32", "sccbf_solve_step_f64",
+           "sccbf_prepare_obs_f32", "sccbf_prepare_obs_f64")
 MOTION_STATIC, MOTION_CONSTANT_VELOCITY, MOTION_SEEKER = 0, 1, 2
 NOMINAL_WAYPOINT_SPEED = 1
 
@@ -93,6 +96,10 @@ def load():
         f = getattr(L, name)
         f.restype = C.c_int
         f.argtypes = [C.c_int64, C.c_int32, vp, vp, C.c_double, C.c_uint32, vp, vp]
+    for name in ("sccbf_prepare_obs_f32", "sccbf_prepare_obs_f64"):
+        f = getattr(L, name)
+        f.restype = C.c_int
+        f.argtypes = [C.c_int64, C.c_int32, vp, vp, C.c_uint32, vp]
     for name in ("sccbf_lane_fit_f32", "sccbf_lane_fit_f64"):
         f = getattr(L, name)
         f.restype = C.c_int

@@ -36,7 +36,7 @@ class BatchedCBF:
     """
 
     def __init__(self, alpha=1.0, lr=1.45, lf=1.45, L=2.9, R=None, dynamics="dbm",
-                 zero_tol=1e-3, lanes_per_qp=0, slip_io=False):
+                 zero_tol=1e-3, lanes_per_qp=0, slip_io=False, streamed_obs=False):
         self._lib = _lib.load()
         self.params = _lib.Params()
         self._lib.sccbf_default_params(C.byref(self.params))
@@ -47,6 +47,8 @@ class BatchedCBF:
         self.params.lanes_per_qp = int(lanes_per_qp)
         # slip_io: u_ref[:,1] / u_out[:,1] are slip angles (DBM) or yaw rates (KBM) already
         self.slip_io = bool(slip_io)
+        # streamed_obs: every call brings obstacle slots that are not read again soon (a performance hint)
+        self.streamed_obs = bool(streamed_obs)
         self.set_qp_cost_weight(np.eye(2) if R is None else R)
 
     # -- setters with the reference's names (cbf/cbf.py:147-157)
@@ -98,7 +100,7 @@ class BatchedCBF:
         A = state.shape[0]
         M = obs.shape[1] if obs.dim() == 5 else obs.shape[0]
         dev = state.device
-        flags = FLAG_SLIP_IO if self.slip_io else 0
+        flags = (FLAG_SLIP_IO if self.slip_io else 0) | (_lib.FLAG_OBS_STREAMED if self.streamed_obs else 0)
         if obs.dim() == 5:
             flags |= FLAG_OBS_TILED
             exp_obs = ((A + 63) // 64, M, 2, 64, 4)
@@ -172,6 +174,45 @@ class BatchedCBF:
                     C.c_void_p(stream))
         _lib.check(rc)
         return u_out, status
+
+
+def prepare_obs(obs, obs_type, agents=None):
+    """As-written ellipse / cone slots -> prepared slots (kinds 4 and 5), IN PLACE on the GPU
+    (sccbf_prepare_obs_*): obs in any of the three layouts, obs_type (M,) or (M, A) uint8 is
+    rewritten to the prepared kinds.  agents: A, needed for tiles whose last tile is partly unused
+    (default: every lane of every tile).  Call it when obstacles change; the filter then does no
+    sine, cosine or reciprocal per slot and tick.  Returns (obs, obs_type)."""
+    if not obs.is_cuda:
+        raise _lib.SccbfError("prepare_obs needs tensors on the GPU (no CPU fallback)")
+    lib = _lib.load()
+    dt, dev = obs.dtype, obs.device
+    flags = 0
+    if obs.dim() == 5:
+        flags |= FLAG_OBS_TILED
+        M, A = obs.shape[1], obs.shape[0] * 64 if agents is None else int(agents)
+        exp = ((A + 63) // 64, M, 2, 64, 4)
+    elif obs.dim() == 3:
+        flags |= FLAG_OBS_SHARED
+        M, A = obs.shape[0], 1
+        exp = (M, 2, 4)
+    else:
+        M, A = obs.shape[0], obs.shape[2]
+        exp = (M, 2, A, 4)
+    if obs_type.dim() == 2:
+        flags |= FLAG_TYPE_PER_AGENT
+        exp_ty = (M, A)
+    else:
+        exp_ty = (M,)
+    if dt not in (torch.float32, torch.float64) or tuple(obs.shape) != exp or not obs.is_contiguous():
+        raise ValueError("obs: expected a contiguous float32 / float64 tensor of shape %s" % (exp,))
+    if (tuple(obs_type.shape) != exp_ty or obs_type.dtype != torch.uint8 or obs_type.device != dev
+            or not obs_type.is_contiguous()):
+        raise ValueError("obs_type: expected contiguous uint8 %s on %s" % (exp_ty, dev))
+    fn = lib.sccbf_prepare_obs_f32 if dt == torch.float32 else lib.sccbf_prepare_obs_f64
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _lib.check(fn(A, M, _ptr(obs), _ptr(obs_type), flags, C.c_void_p(stream)))
+    return obs, obs_type
 
 
 # ---------------------------------------------------------------- slot packing helpers

@@ -81,9 +81,10 @@ int auto_lanes(int64_t A, int M)
     return g;
 }
 
-// Obstacle bytes per launch from which the slots are loaded non-temporally: measured
-// break-even between 34 MB (cached loads 8% faster) and 67 MB (non-temporal 1-4% faster,
-// 5-10% from 134 MB on).
+// Obstacle bytes per launch from which the slots are loaded non-temporally when the caller has
+// not said that they are read once (SCCBF_FLAG_OBS_STREAMED): a batch that is read again on the
+// next tick is better served from the caches up to about the size of the Infinity Cache; batches
+// read once gain from 34 MB on (2-6 % at 65536 agents x 16 slots), 5-10 % from 134 MB on.
 constexpr double kNtBytes = 48.0 * 1024 * 1024;
 
 template <typename T, bool QP_ONLY, int G, int RPL>
@@ -93,7 +94,7 @@ int launch_group(const KArgs<T>& k, hipStream_t s)
     const long long blocks = (k.A + per_block - 1) / per_block;
     if (blocks > 0x7fffffffLL) return SCCBF_ERR_ARG;
     // rows of the QP-only entry are a third of the bytes of obstacle slots: always cached loads
-    const bool nt = !QP_ONLY && (double)k.A * k.M * 8 * sizeof(T) >= kNtBytes;
+    const bool nt = !QP_ONLY && ((k.flags & SCCBF_FLAG_OBS_STREAMED) || (double)k.A * k.M * 8 * sizeof(T) >= kNtBytes);
     if (nt)
         hipLaunchKernelGGL((k_group<T, G, RPL, QP_ONLY, !QP_ONLY>), dim3((unsigned)blocks), dim3(kBlock), 0, s, k.A,
                            k.obs, k.state, k.u_ref, k.obs_type, k.M, k.flags, k);
@@ -409,6 +410,27 @@ int ingest_impl(int64_t A, int32_t M, const T* bbox, const uint8_t* kind, double
 }
 
 template <typename T>
+int prepare_impl(int64_t A, int32_t M, T* obs, uint8_t* obs_type, uint32_t flags, void* stream)
+{
+    if (A < 0 || M < 0 || A > 0x7fffffffLL || M > SCCBF_MAX_ROWS) return SCCBF_ERR_ARG;
+    if (flags & ~(SCCBF_FLAG_TYPE_PER_AGENT | SCCBF_FLAG_OBS_TILED | SCCBF_FLAG_OBS_SHARED)) return SCCBF_ERR_ARG;
+    if ((flags & SCCBF_FLAG_OBS_SHARED) && (flags & (SCCBF_FLAG_OBS_TILED | SCCBF_FLAG_TYPE_PER_AGENT)))
+        return SCCBF_ERR_ARG;
+    if (A == 0 || M == 0) return SCCBF_OK;
+    if (!obs || !obs_type) return SCCBF_ERR_ARG;
+    PArgs<T> k;
+    k.A = (flags & SCCBF_FLAG_OBS_SHARED) ? 1 : A;   // one table: one "agent"
+    k.M = M; k.flags = flags; k.obs = obs; k.type = obs_type;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const long long blocks = (k.A * M + kBlock - 1) / kBlock;
+    if (blocks > 0x7fffffffLL) return SCCBF_ERR_ARG;
+    hipLaunchKernelGGL((k_prepare_obs<T>), dim3((unsigned)blocks), dim3(kBlock), 0, st, k);
+    const long long n = (flags & SCCBF_FLAG_TYPE_PER_AGENT) ? (long long)M * A : M;
+    hipLaunchKernelGGL(k_prepare_types, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, n, obs_type);
+    return hipGetLastError() == hipSuccess ? SCCBF_OK : SCCBF_ERR_LAUNCH;
+}
+
+template <typename T>
 int lane_fit_impl(int64_t A, int32_t K, int32_t degree, const T* px, const T* py, const T* sigma, double buffer,
                   int32_t m, int32_t M, uint32_t flags, T* obs, void* stream)
 {
@@ -448,48 +470,77 @@ int lane_fit_impl(int64_t A, int32_t K, int32_t degree, const T* px, const T* py
 
 extern "C" {
 
+#ifndef SCCBF_ONLY_F64
 int sccbf_ingest_bbox_f32(int64_t A, int32_t M, const float* bbox, const uint8_t* kind, double buffer,
                           uint32_t flags, float* obs, void* stream)
 {
     return ingest_impl<float>(A, M, bbox, kind, buffer, flags, obs, stream);
 }
+#endif
 
+#ifndef SCCBF_ONLY_F32
 int sccbf_ingest_bbox_f64(int64_t A, int32_t M, const double* bbox, const uint8_t* kind, double buffer,
                           uint32_t flags, double* obs, void* stream)
 {
     return ingest_impl<double>(A, M, bbox, kind, buffer, flags, obs, stream);
 }
+#endif
 
+#ifndef SCCBF_ONLY_F64
+int sccbf_prepare_obs_f32(int64_t A, int32_t M, float* obs, uint8_t* obs_type, uint32_t flags, void* stream)
+{
+    return prepare_impl<float>(A, M, obs, obs_type, flags, stream);
+}
+#endif
+
+#ifndef SCCBF_ONLY_F32
+int sccbf_prepare_obs_f64(int64_t A, int32_t M, double* obs, uint8_t* obs_type, uint32_t flags, void* stream)
+{
+    return prepare_impl<double>(A, M, obs, obs_type, flags, stream);
+}
+#endif
+
+#ifndef SCCBF_ONLY_F64
 int sccbf_lane_fit_f32(int64_t A, int32_t K, int32_t degree, const float* px, const float* py,
                        const float* sigma, double buffer, int32_t m, int32_t M, uint32_t flags, float* obs,
                        void* stream)
 {
     return lane_fit_impl<float>(A, K, degree, px, py, sigma, buffer, m, M, flags, obs, stream);
 }
+#endif
 
+#ifndef SCCBF_ONLY_F32
 int sccbf_lane_fit_f64(int64_t A, int32_t K, int32_t degree, const double* px, const double* py,
                        const double* sigma, double buffer, int32_t m, int32_t M, uint32_t flags, double* obs,
                        void* stream)
 {
     return lane_fit_impl<double>(A, K, degree, px, py, sigma, buffer, m, M, flags, obs, stream);
 }
+#endif
 
+#ifndef SCCBF_ONLY_F64
 int sccbf_solve_step_f32(const sccbf_params* p, double max_steer, double dt, int64_t A, int32_t M, float* state,
                          const float* u_ref, const float* obs, const uint8_t* obs_type, float* u_out,
                          int32_t* status, float* beta_out, void* stream)
 {
     return solve_step_impl<float>(p, max_steer, dt, A, M, state, u_ref, obs, obs_type, u_out, status, beta_out, stream);
 }
+#endif
 
+#ifndef SCCBF_ONLY_F32
 int sccbf_solve_step_f64(const sccbf_params* p, double max_steer, double dt, int64_t A, int32_t M, double* state,
                          const double* u_ref, const double* obs, const uint8_t* obs_type, double* u_out,
                          int32_t* status, double* beta_out, void* stream)
 {
     return solve_step_impl<double>(p, max_steer, dt, A, M, state, u_ref, obs, obs_type, u_out, status, beta_out, stream);
 }
+#endif
 
+#ifndef SCCBF_ONLY_F64
 int sccbf_version(void) { return SCCBF_VERSION; }
+#endif
 
+#ifndef SCCBF_ONLY_F64
 const char* sccbf_strerror(int code)
 {
     switch (code) {
@@ -503,7 +554,9 @@ const char* sccbf_strerror(int code)
     default: return "unknown error";
     }
 }
+#endif
 
+#ifndef SCCBF_ONLY_F64
 void sccbf_default_params(sccbf_params* p)
 {
     if (!p) return;
@@ -518,59 +571,77 @@ void sccbf_default_params(sccbf_params* p)
     p->flags = 0;
     p->reserved = 0;
 }
+#endif
 
+#ifndef SCCBF_ONLY_F64
 int sccbf_solve_f32(const sccbf_params* p, int64_t A, int32_t M, const float* state,
                     const float* u_ref, const float* obs, const uint8_t* obs_type, float* u_out,
                     int32_t* status, float* rows_out, void* stream)
 {
     return solve_impl<float>(p, A, M, state, u_ref, obs, obs_type, u_out, status, rows_out, stream);
 }
+#endif
 
+#ifndef SCCBF_ONLY_F32
 int sccbf_solve_f64(const sccbf_params* p, int64_t A, int32_t M, const double* state,
                     const double* u_ref, const double* obs, const uint8_t* obs_type, double* u_out,
                     int32_t* status, double* rows_out, void* stream)
 {
     return solve_impl<double>(p, A, M, state, u_ref, obs, obs_type, u_out, status, rows_out, stream);
 }
+#endif
 
+#ifndef SCCBF_ONLY_F64
 int sccbf_solve_sa_f32(const sccbf_params* p, double dt, int64_t A, int32_t M, const float* state,
                        float* slip, const float* u_ref, const float* obs, const uint8_t* obs_type,
                        float* u_out, int32_t* status, float* rows_out, void* stream)
 {
     return solve_sa_impl<float>(p, dt, A, M, state, slip, u_ref, obs, obs_type, u_out, status, rows_out, stream);
 }
+#endif
 
+#ifndef SCCBF_ONLY_F32
 int sccbf_solve_sa_f64(const sccbf_params* p, double dt, int64_t A, int32_t M, const double* state,
                        double* slip, const double* u_ref, const double* obs, const uint8_t* obs_type,
                        double* u_out, int32_t* status, double* rows_out, void* stream)
 {
     return solve_sa_impl<double>(p, dt, A, M, state, slip, u_ref, obs, obs_type, u_out, status, rows_out, stream);
 }
+#endif
 
+#ifndef SCCBF_ONLY_F64
 int sccbf_qp_f32(const sccbf_params* p, int64_t A, int32_t M, const float* rows, const float* u_nom,
                  float* u_out, int32_t* status, void* stream)
 {
     return qp_impl<float>(p, A, M, rows, u_nom, u_out, status, stream);
 }
+#endif
 
+#ifndef SCCBF_ONLY_F32
 int sccbf_qp_f64(const sccbf_params* p, int64_t A, int32_t M, const double* rows,
                  const double* u_nom, double* u_out, int32_t* status, void* stream)
 {
     return qp_impl<double>(p, A, M, rows, u_nom, u_out, status, stream);
 }
+#endif
 
+#ifndef SCCBF_ONLY_F64
 int sccbf_partials_f32(const sccbf_params* p, int64_t A, int32_t M, const float* state,
                        const float* obs, const uint8_t* obs_type, float* out, void* stream)
 {
     return partials_impl<float>(p, A, M, state, obs, obs_type, out, stream);
 }
+#endif
 
+#ifndef SCCBF_ONLY_F32
 int sccbf_partials_f64(const sccbf_params* p, int64_t A, int32_t M, const double* state,
                        const double* obs, const uint8_t* obs_type, double* out, void* stream)
 {
     return partials_impl<double>(p, A, M, state, obs, obs_type, out, stream);
 }
+#endif
 
+#ifndef SCCBF_ONLY_F64
 void sccbf_default_nominal_params(sccbf_nominal_params* p)
 {
     if (!p) return;
@@ -585,31 +656,41 @@ void sccbf_default_nominal_params(sccbf_nominal_params* p)
     p->flags = 0;
     p->reserved = 0;
 }
+#endif
 
+#ifndef SCCBF_ONLY_F64
 int sccbf_nominal_f32(const sccbf_nominal_params* p, int64_t A, int32_t N, const float* state,
                       const float* traj, int32_t* target_idx, float* pid_state, float* u_ref, void* stream)
 {
     return nominal_impl<float>(p, A, N, state, traj, target_idx, pid_state, u_ref, stream);
 }
+#endif
 
+#ifndef SCCBF_ONLY_F32
 int sccbf_nominal_f64(const sccbf_nominal_params* p, int64_t A, int32_t N, const double* state,
                       const double* traj, int32_t* target_idx, double* pid_state, double* u_ref, void* stream)
 {
     return nominal_impl<double>(p, A, N, state, traj, target_idx, pid_state, u_ref, stream);
 }
+#endif
 
+#ifndef SCCBF_ONLY_F64
 int sccbf_vehicle_step_f32(int64_t A, float* state, const float* u, double lr, double lf, double max_steer,
                            double dt, float* beta_out, void* stream)
 {
     return vehicle_step_impl<float>(A, state, u, lr, lf, max_steer, dt, beta_out, stream);
 }
+#endif
 
+#ifndef SCCBF_ONLY_F32
 int sccbf_vehicle_step_f64(int64_t A, double* state, const double* u, double lr, double lf, double max_steer,
                            double dt, double* beta_out, void* stream)
 {
     return vehicle_step_impl<double>(A, state, u, lr, lf, max_steer, dt, beta_out, stream);
 }
+#endif
 
+#ifndef SCCBF_ONLY_F64
 void sccbf_default_rollout_params(sccbf_rollout_params* p)
 {
     if (!p) return;
@@ -620,7 +701,9 @@ void sccbf_default_rollout_params(sccbf_rollout_params* p)
     p->seek_gain = 0.2;
     p->seek_v_min = 3.0;
 }
+#endif
 
+#ifndef SCCBF_ONLY_F64
 int sccbf_rollout_f32(const sccbf_params* p, const sccbf_nominal_params* np, const sccbf_rollout_params* rp,
                       int64_t A, int32_t M, int32_t N, float* state, const float* traj, int32_t* target_idx,
                       float* pid_state, const float* obs, const uint8_t* obs_type, float* h_min,
@@ -629,7 +712,9 @@ int sccbf_rollout_f32(const sccbf_params* p, const sccbf_nominal_params* np, con
     return rollout_impl<float>(p, np, rp, A, M, N, state, traj, target_idx, pid_state, obs, obs_type, h_min,
                                n_active, n_infeasible, trace, stream);
 }
+#endif
 
+#ifndef SCCBF_ONLY_F32
 int sccbf_rollout_f64(const sccbf_params* p, const sccbf_nominal_params* np, const sccbf_rollout_params* rp,
                       int64_t A, int32_t M, int32_t N, double* state, const double* traj, int32_t* target_idx,
                       double* pid_state, const double* obs, const uint8_t* obs_type, double* h_min,
@@ -638,5 +723,6 @@ int sccbf_rollout_f64(const sccbf_params* p, const sccbf_nominal_params* np, con
     return rollout_impl<double>(p, np, rp, A, M, N, state, traj, target_idx, pid_state, obs, obs_type, h_min,
                                 n_active, n_infeasible, trace, stream);
 }
+#endif
 
 }  // extern "C"

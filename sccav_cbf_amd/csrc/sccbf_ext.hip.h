@@ -33,6 +33,12 @@ __device__ inline void ext_slot_row_(int type, T (&o)[8], const Ego<T>& e, const
         break;
     case SCCBF_OBS_LANE: lane_(e.x, e.y, o, p.zero_tol, d); break;
     case SCCBF_OBS_RADIAL: radial_(e.x, e.y, e.v, o, d); break;
+    case SCCBF_OBS_ELLIPSE_PREP: ellipse_prep_(e.x, e.y, o, d); break;
+    case SCCBF_OBS_CONE_PREP:
+        // the obstacle's velocity was resolved with the slot's own beta: the slot keeps it
+        cone_prep_(e.x, e.y, e.th, e.v, e.cth, e.sth, o, p.zero_tol, d);
+        hb = d.hth;
+        break;
     default:
         a0 = T(0); a1 = T(0); b = T(-1); h = T(1);
         return;
@@ -70,6 +76,7 @@ __global__ __launch_bounds__(kBlock) void k_group_ext(const KArgs<T> p, const XA
     int bad = !(finite_(ur0) && finite_(ur1) && finite_(e.x) && finite_(e.y) && finite_(e.th) && finite_(e.v) &&
                 finite_(sl.x) && finite_(sl.y));
     sincos_(e.th, &e.sth, &e.cth);
+    e.derive(p);
     T beta_ref = T(0), cthb = e.cth, sthb = e.sth, sb = T(0);
     e.un0 = ur0;
     e.un1 = ur1;

@@ -46,11 +46,67 @@ __global__ __launch_bounds__(kBlock) void k_ingest(const IArgs<T> p)
     } else if (kind == SCCBF_OBS_CONE) {
         oa = v4{b0.x, b0.y, T(0), b1.y};
         ob = v4{sqrt_(b0.z * b0.z + b0.w * b0.w) + p.buffer, T(0), T(0), T(0)};
+    } else if (kind == SCCBF_OBS_ELLIPSE_PREP) {  // the same ellipse, constants evaluated (in double)
+        const double a = (double)(b0.z + p.buffer), b = (double)(b0.w + p.buffer);
+        oa = v4{b0.x, b0.y, (T)(1.0 / (a * a)), (T)(1.0 / (b * b))};
+        ob = v4{(T)cos((double)b1.x), (T)sin((double)b1.x), T(0), T(0)};
+    } else if (kind == SCCBF_OBS_CONE_PREP) {     // theta_o = 0, beta = 0: the velocity is (speed, 0)
+        oa = v4{b0.x, b0.y, b1.y, T(0)};
+        ob = v4{sqrt_(b0.z * b0.z + b0.w * b0.w) + p.buffer, T(0), T(0), T(0)};
     }
     const ObsAddr ad = slot_addr_<T>(p.A, p.M, p.flags, a);
     v4* out = reinterpret_cast<v4*>(p.obs);
     out[ad.at(m)] = oa;
     out[ad.at(m) + ad.half] = ob;
+}
+
+// As-written ellipse / cone slots -> prepared slots, in place; one thread per (slot, agent).  The
+// constants are evaluated in double whatever T is: this runs once per obstacle update, not per tick.
+template <typename T> struct PArgs {
+    long long A;
+    int M;
+    unsigned flags;
+    T* obs;
+    uint8_t* type;
+};
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_prepare_obs(const PArgs<T> p)
+{
+    using v4 = typename VT<T>::v4;
+    const long long gid = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (gid >= p.A * p.M) return;
+    const int m = (int)(gid / p.A);
+    const long long a = gid % p.A;
+    const int kind = (p.flags & SCCBF_FLAG_TYPE_PER_AGENT) ? p.type[(long long)m * p.A + a] : p.type[m];
+    if (kind != SCCBF_OBS_ELLIPSE && kind != SCCBF_OBS_CONE) return;
+    KArgs<T> k;
+    k.A = p.A; k.M = p.M; k.flags = p.flags & (SCCBF_FLAG_OBS_TILED | SCCBF_FLAG_OBS_SHARED);
+    const ObsAddr ad = obs_addr_(k, a);
+    v4* obs = reinterpret_cast<v4*>(p.obs);
+    v4 oa = obs[ad.at(m)], ob = obs[ad.at(m) + ad.half];
+    if (kind == SCCBF_OBS_ELLIPSE) {
+        const double ea = (double)oa.z, eb = (double)oa.w, th = (double)ob.x;
+        oa.z = (T)(1.0 / (ea * ea));
+        oa.w = (T)(1.0 / (eb * eb));
+        ob = v4{(T)cos(th), (T)sin(th), ob.y, ob.z};
+    } else {
+        const double ang = (double)oa.z + (double)ob.y, vo = (double)oa.w;
+        oa.z = (T)(vo * cos(ang));
+        oa.w = (T)(vo * sin(ang));
+    }
+    obs[ad.at(m)] = oa;
+    obs[ad.at(m) + ad.half] = ob;
+}
+
+// after k_prepare_obs (same stream): the kinds of the slots it rewrote
+__global__ __launch_bounds__(kBlock) void k_prepare_types(long long n, uint8_t* type)
+{
+    const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const int k = type[i];
+    if (k == SCCBF_OBS_ELLIPSE) type[i] = SCCBF_OBS_ELLIPSE_PREP;
+    if (k == SCCBF_OBS_CONE) type[i] = SCCBF_OBS_CONE_PREP;
 }
 
 template <typename T> struct FArgs {

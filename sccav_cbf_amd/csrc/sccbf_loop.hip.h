@@ -303,6 +303,12 @@ __device__ inline void advance_slot_(int type, typename VT<T>::v4& oa, typename 
     } else if (type == SCCBF_OBS_RADIAL) {
         oa.x += ob.x * dt;
         oa.y += ob.y * dt;
+    } else if (type == SCCBF_OBS_ELLIPSE_PREP) {
+        oa.x += ob.z * dt;
+        oa.y += ob.w * dt;
+    } else if (type == SCCBF_OBS_CONE_PREP) {
+        oa.x += oa.z * dt;
+        oa.y += oa.w * dt;
     }
 }
 
@@ -313,7 +319,7 @@ template <typename T>
 __device__ inline void seek_slot_(int type, typename VT<T>::v4& oa, typename VT<T>::v4& ob, T x, T y, T gain,
                                   T v_min, T dt)
 {
-    if (type != SCCBF_OBS_ELLIPSE && type != SCCBF_OBS_RADIAL) {
+    if (type != SCCBF_OBS_ELLIPSE && type != SCCBF_OBS_RADIAL && type != SCCBF_OBS_ELLIPSE_PREP) {
         advance_slot_<T>(type, oa, ob, dt);
         return;
     }
@@ -326,6 +332,11 @@ __device__ inline void seek_slot_(int type, typename VT<T>::v4& oa, typename VT<
         ob.x = atan2_(dy, dx);
         ob.y = vx;
         ob.z = vy;
+    } else if (type == SCCBF_OBS_ELLIPSE_PREP) {  // the new heading's cosine and sine, directly
+        ob.x = d2 > T(0) ? dx * inv : T(1);
+        ob.y = dy * inv;
+        ob.z = vx;
+        ob.w = vy;
     } else {
         ob.x = vx;
         ob.y = vy;

@@ -28,6 +28,25 @@ __device__ inline void ellipse_(T x, T y, const T o[8], Partials<T>& r)
     r.ht = T(-2) * (xd * ia2 * o[5] + yd * ib2 * o[6]);
 }
 
+// Ellipse2D whose per-obstacle constants are already evaluated (SCCBF_OBS_ELLIPSE_PREP):
+// o = cx, cy, 1/a^2, 1/b^2, cos(theta_o), sin(theta_o), vx, vy.  Same formulas as ellipse_,
+// without the sine / cosine / reciprocals of values that do not depend on the agent.
+template <typename T>
+__device__ inline void ellipse_prep_(T x, T y, const T o[8], Partials<T>& r)
+{
+    T xd = x - o[0], yd = y - o[1];
+    T ia2 = o[2], ib2 = o[3], ct = o[4], st = o[5];
+    T p = xd * ct + yd * st;
+    T q = -xd * st + yd * ct;
+    T pa = p * ia2, qb = q * ib2;
+    r.h = p * pa + q * qb - T(1);
+    r.hx = T(2) * (ct * pa - st * qb);
+    r.hy = T(2) * (st * pa + ct * qb);
+    r.hth = T(0);
+    r.hv = T(0);
+    r.ht = T(-2) * (xd * ia2 * o[6] + yd * ib2 * o[7]);
+}
+
 // Time-varying ellipse with speed margin, reference
 // test_scripts/radial_dynamic_obstacles.py:391-405.
 template <typename T>
@@ -44,17 +63,13 @@ __device__ inline void radial_(T x, T y, T v, const T o[8], Partials<T>& r)
     r.ht = T(-2) * (xd * ia2 * o[4] + yd * ib2 * o[5]);
 }
 
-// CollisionCone2D, reference cbf/obstacles.py:468-502 (state), 401-458 (partials).
+// CollisionCone2D, reference cbf/obstacles.py:468-502 (state), 401-458 (partials), from the
+// relative position (xd, yd), the agent's velocity (svx, svy), the obstacle's (ovx, ovy), the cone
+// radius a and (c, sn) = cos, sin of the agent's heading plus the cone's beta.
 template <typename T>
-__device__ inline void cone_(T x, T y, T th, T v, T cth, T sth, const T o[8], T eps,
-                             Partials<T>& r)
+__device__ inline void cone_core_(T xd, T yd, T svx, T svy, T ovx, T ovy, T a, T c, T sn, T eps,
+                                  Partials<T>& r)
 {
-    T xd = x - o[0], yd = y - o[1];
-    T beta = o[5], a = o[4];
-    T svx = v * cth, svy = v * sth;
-    T so, co;
-    sincos_(o[2] + beta, &so, &co);
-    T ovx = o[3] * co, ovy = o[3] * so;
     T dvx = svx - ovx, dvy = svy - ovy;
     T d2 = xd * xd + yd * yd;
     T dist = sqrt_(d2);
@@ -62,8 +77,6 @@ __device__ inline void cone_(T x, T y, T th, T v, T cth, T sth, const T o[8], T 
     T cb = eps;
     if (dist > abs_(a)) cb = sqrt_(d2 - a * a) + eps;
     T cos_phi = (dist > eps) ? div_(cb, dist) : T(0);
-    T c = cth, sn = sth;
-    if (beta != T(0)) sincos_(th + beta, &sn, &c);
     T icb = rcp_(cb + eps);
     T cbn = div_(cb, vn + eps);
     r.h = (xd * dvx + yd * dvy) + dist * vn * cos_phi;
@@ -72,6 +85,31 @@ __device__ inline void cone_(T x, T y, T th, T v, T cth, T sth, const T o[8], T 
     r.hv = (xd * c + yd * sn) + (dvx * c + dvy * sn) * cbn;
     r.hth = (-xd * svy + yd * svx) + (-dvx * svy + dvy * svx) * cbn;
     r.ht = (-dvx * ovx - dvy * ovy) - vn * (xd * ovx + yd * ovy) * icb;
+}
+
+// o = cx, cy, theta_o, v_o, a, beta (SCCBF_OBS_CONE)
+template <typename T>
+__device__ inline void cone_(T x, T y, T th, T v, T cth, T sth, const T o[8], T eps,
+                             Partials<T>& r)
+{
+    T beta = o[5];
+    T so, co;
+    sincos_(o[2] + beta, &so, &co);
+    T c = cth, sn = sth;
+    if (beta != T(0)) sincos_(th + beta, &sn, &c);
+    cone_core_(x - o[0], y - o[1], v * cth, v * sth, o[3] * co, o[3] * so, o[4], c, sn, eps, r);
+}
+
+// o = cx, cy, v_o cos(theta_o + beta), v_o sin(theta_o + beta), a, beta (SCCBF_OBS_CONE_PREP):
+// the obstacle's velocity is already resolved, beta only turns the direction of dh/dv
+template <typename T>
+__device__ inline void cone_prep_(T x, T y, T th, T v, T cth, T sth, const T o[8], T eps,
+                                  Partials<T>& r)
+{
+    T beta = o[5];
+    T c = cth, sn = sth;
+    if (beta != T(0)) sincos_(th + beta, &sn, &c);
+    cone_core_(x - o[0], y - o[1], v * cth, v * sth, o[2], o[3], o[4], c, sn, eps, r);
 }
 
 template <typename T> __device__ inline void poly3_(const T c[4], T x, T& f, T& df, T& ddf)
@@ -141,7 +179,15 @@ __device__ inline void lane_(T x, T y, const T o[8], T eps, Partials<T>& r)
 // Per-agent quantities every row needs.
 template <typename T> struct Ego {
     T x, y, th, v, cth, sth;
+    T evx, evy;  // velocity v (cos, sin)(th)
+    T vlr;       // v / lr
     T un0, un1;  // nominal input in QP coordinates
+    __device__ void derive(const KArgs<T>& p)
+    {
+        evx = v * cth;
+        evy = v * sth;
+        vlr = v * p.inv_lr;
+    }
 };
 
 // Where the two 4-vectors of slot m of agent a live, in units of 4-vectors:
@@ -166,22 +212,12 @@ template <typename T> __device__ inline ObsAddr obs_addr_(const KArgs<T>& p, lon
     return r;
 }
 
-// One obstacle slot -> constraint row  a . u >= b  (u-space) and barrier value h.
+// Partials -> constraint row  a . u >= b  (u-space).
 // DBM contraction: reference cbf/cbf.py:159-164, 200-207.  KBM: cbf/cbf.py:94-101.
 template <typename T>
-__device__ inline void slot_row_(int type, const T o[8], const Ego<T>& e, const KArgs<T>& p,
-                                 T& a0, T& a1, T& b, T& h)
+__device__ inline void contract_row_(const Partials<T>& d, const Ego<T>& e, const KArgs<T>& p,
+                                     T& a0, T& a1, T& b, T& h)
 {
-    Partials<T> d;
-    switch (type) {
-    case SCCBF_OBS_ELLIPSE: ellipse_(e.x, e.y, o, d); break;
-    case SCCBF_OBS_CONE: cone_(e.x, e.y, e.th, e.v, e.cth, e.sth, o, p.zero_tol, d); break;
-    case SCCBF_OBS_LANE: lane_(e.x, e.y, o, p.zero_tol, d); break;
-    case SCCBF_OBS_RADIAL: radial_(e.x, e.y, e.v, o, d); break;
-    default:
-        a0 = T(0); a1 = T(0); b = T(-1); h = T(1);
-        return;
-    }
     h = d.h;
     if (p.dynamics == SCCBF_DYN_KBM) {
         a0 = e.cth * d.hx + e.sth * d.hy;
@@ -189,13 +225,41 @@ __device__ inline void slot_row_(int type, const T o[8], const Ego<T>& e, const 
         b = -(p.alpha * d.h);
     } else {
         a0 = d.hv;
-        a1 = e.v * (-e.sth * d.hx + e.cth * d.hy) + (e.v * p.inv_lr) * d.hth;
-        T lf_h = e.v * (e.cth * d.hx + e.sth * d.hy);
+        a1 = (e.evx * d.hy - e.evy * d.hx) + e.vlr * d.hth;
+        T lf_h = e.evx * d.hx + e.evy * d.hy;
         b = -(lf_h + p.alpha * d.h + d.ht);
     }
 }
 
-// u-space row -> unit-normal row in w-space; zero rows keep at = 0.
+// Barrier value and partials of one slot whose kind is known; false for an empty slot.
+template <typename T>
+__device__ inline bool slot_partials_(int type, const T o[8], const Ego<T>& e, const KArgs<T>& p, Partials<T>& d)
+{
+    switch (type) {
+    case SCCBF_OBS_ELLIPSE: ellipse_(e.x, e.y, o, d); return true;
+    case SCCBF_OBS_CONE: cone_(e.x, e.y, e.th, e.v, e.cth, e.sth, o, p.zero_tol, d); return true;
+    case SCCBF_OBS_LANE: lane_(e.x, e.y, o, p.zero_tol, d); return true;
+    case SCCBF_OBS_RADIAL: radial_(e.x, e.y, e.v, o, d); return true;
+    case SCCBF_OBS_ELLIPSE_PREP: ellipse_prep_(e.x, e.y, o, d); return true;
+    case SCCBF_OBS_CONE_PREP: cone_prep_(e.x, e.y, e.th, e.v, e.cth, e.sth, o, p.zero_tol, d); return true;
+    default: return false;
+    }
+}
+
+// One obstacle slot -> constraint row  a . u >= b  (u-space) and barrier value h.
+template <typename T>
+__device__ inline void slot_row_(int type, const T o[8], const Ego<T>& e, const KArgs<T>& p,
+                                 T& a0, T& a1, T& b, T& h)
+{
+    Partials<T> d;
+    if (!slot_partials_(type, o, e, p, d)) {
+        a0 = T(0); a1 = T(0); b = T(-1); h = T(1);
+        return;
+    }
+    contract_row_(d, e, p, a0, a1, b, h);
+}
+
+// u-space row -> unit-normal row in w-space; zero rows keep at = 0.  Straight-line code.
 template <typename T>
 __device__ inline void to_wspace_(T a0, T a1, T b, const Ego<T>& e, const KArgs<T>& p,
                                   T& at0, T& at1, T& bt)
@@ -204,18 +268,14 @@ __device__ inline void to_wspace_(T a0, T a1, T b, const Ego<T>& e, const KArgs<
     T t1 = (a1 - p.l10 * t0) * p.inv_l11;
     T rhs = b - (a0 * e.un0 + a1 * e.un1);
     T n2 = t0 * t0 + t1 * t1;
-    if (n2 > Lim<T>::tiny_n2) {
-        T inv = rsqrt_(n2);
-        at0 = t0 * inv;
-        at1 = t1 * inv;
-        bt = rhs * inv;
-    } else {
-        // 0 . u >= rhs holds for every u or for none: a positive rhs must win every comparison of
-        // violations, whatever tolerance the size of w has earned the other rows by then
-        at0 = T(0);
-        at1 = T(0);
-        bt = rhs > Lim<T>::tiny_n2 ? T(INFINITY) : rhs;
-    }
+    const bool nz = n2 > Lim<T>::tiny_n2;
+    T inv = nz ? rsqrt_(n2) : T(0);
+    // 0 . u >= rhs holds for every u or for none: a positive rhs must win every comparison of
+    // violations, whatever tolerance the size of w has earned the other rows by then
+    T zb = rhs > Lim<T>::tiny_n2 ? T(INFINITY) : rhs;
+    at0 = nz ? t0 * inv : T(0);
+    at1 = nz ? t1 * inv : T(0);
+    bt = nz ? rhs * inv : zb;
 }
 
 // Ego quantities from the already loaded state / nominal-input vectors.
@@ -231,6 +291,7 @@ __device__ inline void make_ego_(const KArgs<T>& p, const typename VT<T>::v4& s,
         e.x = e.y = e.th = e.v = T(0);
         e.cth = T(1);
         e.sth = T(0);
+        e.evx = e.evy = e.vlr = T(0);
         e.un0 = ur0;
         e.un1 = ur1;
         return;
@@ -238,6 +299,7 @@ __device__ inline void make_ego_(const KArgs<T>& p, const typename VT<T>::v4& s,
     e.x = s.x; e.y = s.y; e.th = s.z; e.v = s.w;
     bad |= !(finite_(s.x) && finite_(s.y) && finite_(s.z) && finite_(s.w));
     sincos_(e.th, &e.sth, &e.cth);
+    e.derive(p);
     e.un0 = ur0;
     if (p.flags & SCCBF_FLAG_SLIP_IO)
         e.un1 = ur1;

@@ -11,6 +11,7 @@ Every generator returns a dict: state (A,4), u_ref (A,2), obs (M,2,A,4), obs_typ
 import numpy as np
 
 OBS_ELLIPSE, OBS_CONE, OBS_LANE, OBS_RADIAL, OBS_EMPTY = 0, 1, 2, 3, 255
+OBS_ELLIPSE_PREP, OBS_CONE_PREP = 4, 5
 
 MAX_STEER = np.radians(30.0)
 TARGET_SPEED = 30.0 / 3.6
@@ -21,6 +22,38 @@ def _pack(slots):
     """(M, A, 8) -> (M, 2, A, 4)"""
     M, A, _ = slots.shape
     return np.ascontiguousarray(slots.reshape(M, A, 2, 4).transpose(0, 2, 1, 3))
+
+
+def prepared(w):
+    """The same batch with every ellipse and cone slot in its prepared form (kinds 4 and 5 of
+    include/sccbf.h): what does not depend on the agent is evaluated once, here in float64,
+        ellipse  cx, cy, a, b, theta_o, vx, vy, -        ->  cx, cy, 1/a^2, 1/b^2, cos, sin, vx, vy
+        cone     cx, cy, theta_o, v_o, a, beta, -, -     ->  cx, cy, v_o cos(theta_o + beta), v_o sin(..), a, beta, -, -
+    obs (M,2,A,4) and obs_type (M,) or (M,A); other slots are kept."""
+    obs = np.array(w["obs"], dtype=np.float64)
+    ty = np.array(w["obs_type"], dtype=np.uint8)
+    M, _, A, _ = obs.shape
+    sl = np.concatenate([obs[:, 0], obs[:, 1]], axis=2)            # (M, A, 8)
+    kind = np.broadcast_to(ty.reshape(M, -1), (M, A))
+    out = sl.copy()
+    e, c = kind == OBS_ELLIPSE, kind == OBS_CONE
+    with np.errstate(divide="ignore", invalid="ignore"):
+        out[..., 2] = np.where(e, 1.0 / (sl[..., 2] * sl[..., 2]), out[..., 2])
+        out[..., 3] = np.where(e, 1.0 / (sl[..., 3] * sl[..., 3]), out[..., 3])
+    out[..., 4] = np.where(e, np.cos(sl[..., 4]), out[..., 4])
+    out[..., 5] = np.where(e, np.sin(sl[..., 4]), out[..., 5])
+    out[..., 6] = np.where(e, sl[..., 5], out[..., 6])
+    out[..., 7] = np.where(e, sl[..., 6], out[..., 7])
+    ang = sl[..., 2] + sl[..., 5]
+    out[..., 2] = np.where(c, sl[..., 3] * np.cos(ang), out[..., 2])
+    out[..., 3] = np.where(c, sl[..., 3] * np.sin(ang), out[..., 3])
+    ty2 = ty.copy()
+    ty2[ty == OBS_ELLIPSE] = OBS_ELLIPSE_PREP
+    ty2[ty == OBS_CONE] = OBS_CONE_PREP
+    r = dict(w)
+    r["obs"] = _pack(out)
+    r["obs_type"] = ty2
+    return r
 
 
 def spline_course():

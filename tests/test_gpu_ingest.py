@@ -31,7 +31,7 @@ def _boxes(A, M, seed):
 def test_ingest_bbox_matches_oracle(oracle, dtype, per_agent, A):
     M = 7
     bbox, rng = _boxes(A, M, 3)
-    kind = rng.choice(np.array([0, 1, 255], dtype=np.uint8), (M, A) if per_agent else (M,))
+    kind = rng.choice(np.array([0, 1, 4, 5, 255], dtype=np.uint8), (M, A) if per_agent else (M,))   # 4, 5: prepared forms
     exp = oracle.ingest_bbox(bbox, kind, buffer=0.7)
     b = torch.from_numpy(bbox).to(DEV).to(dtype)
     k = torch.from_numpy(kind).to(DEV)

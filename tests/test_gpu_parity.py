@@ -108,6 +108,9 @@ SCENARIOS = {
     "ellipse8": lambda: scenarios.config3(A=4096),
     "lanes2_cones6": lambda: scenarios.lanes_and_cones(A=4096),
     "radial32": lambda: scenarios.radial_seekers(M=32, A=257, seed=5),
+    # the same obstacles with their per-obstacle constants evaluated into the slot (kinds 4, 5)
+    "mixed16_prepared": lambda: scenarios.prepared(scenarios.config4(A=4096, nominal="uniform")),
+    "lanes2_cones6_prepared": lambda: scenarios.prepared(scenarios.lanes_and_cones(A=4096)),
 }
 
 
@@ -442,3 +445,68 @@ def test_batch_beyond_4_gib_of_obstacles(oracle, layout):
     del obs
     uo, so, ro = _orc_solve(oracle, w)
     _check(u[idx].double().cpu().numpy(), st[idx].cpu().numpy(), uo, so, ro, w["u_ref"], torch.float32)
+
+
+def _mixed_kinds(A=1500, seed=77):
+    """Every kind side by side in one batch, kinds per agent: lanes of a wavefront hold different kinds."""
+    w = scenarios.config4(A=A, nominal="uniform", seed=seed)
+    wp = scenarios.prepared(w)
+    rng = np.random.default_rng(seed)
+    M = w["obs"].shape[0]
+    pick = rng.random((M, A)) < 0.5
+    obs = np.where(pick[:, None, :, None], wp["obs"], w["obs"])
+    ty = np.where(pick, wp["obs_type"][:, None], w["obs_type"][:, None]).astype(np.uint8)
+    ty[rng.random((M, A)) < 0.1] = 255
+    return dict(state=w["state"], u_ref=w["u_ref"], obs=np.ascontiguousarray(obs), obs_type=np.ascontiguousarray(ty))
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("lanes", (0, 1, 4, 16, 64))
+def test_prepared_and_written_slots_side_by_side(oracle, dtype, lanes):
+    w = _mixed_kinds()
+    uo, so, ro = _orc_solve(oracle, w, extra_flags=oracle.FLAG_TYPE_PER_AGENT)
+    ug, sg, rg = _gpu_solve(w, dtype, lanes)
+    _check(ug, sg, uo, so, ro, w["u_ref"], dtype)
+    tol = 1e-9 if dtype == torch.float64 else 1e-3
+    assert (np.abs(rg - ro) / (np.abs(ro).max(axis=2, keepdims=True) + 1.0)).max() <= tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("layout", ["planes", "tiles", "shared", "per_agent_types"])
+def test_prepare_obs_on_the_device_equals_the_host_restatement(dtype, layout):
+    """sccbf_prepare_obs_* rewrites slots and kinds in place; checked against scenarios.prepared."""
+    from sccav_cbf_amd.batched import planes_to_tiled, prepare_obs
+    A = 1 if layout == "shared" else 333
+    w = scenarios.lanes_and_cones(A=A, n_cone=5)
+    e = scenarios.config3(A=A)
+    w["obs"] = np.concatenate([w["obs"], e["obs"][:3]], axis=0)          # lanes, cones, ellipses
+    w["obs_type"] = np.concatenate([w["obs_type"], e["obs_type"][:3]])
+    if layout == "per_agent_types":
+        ty = np.repeat(w["obs_type"][:, None], A, axis=1)
+        ty[:, ::7] = 255
+        w["obs_type"] = np.ascontiguousarray(ty)
+    t = _to_dev(w, dtype)
+    host = {k: (v.cpu().double().numpy() if v.dtype.is_floating_point else v.cpu().numpy()) for k, v in t.items()}
+    want = scenarios.prepared(host)                     # from the values the device holds
+    obs, ty = t["obs"], t["obs_type"]
+    if layout == "tiles":
+        obs = planes_to_tiled(obs)
+    elif layout == "shared":
+        obs = obs[:, :, 0, :].contiguous()
+    prepare_obs(obs, ty, agents=A)
+    torch.cuda.synchronize()
+    got = obs
+    if layout == "tiles":
+        M = obs.shape[1]
+        got = obs.permute(1, 2, 0, 3, 4).reshape(M, 2, -1, 4)[:, :, :A]
+    elif layout == "shared":
+        got = obs[:, :, None, :]
+    got = got.double().cpu().numpy()
+    assert np.array_equal(ty.cpu().numpy(), want["obs_type"])
+    rel = np.abs(got - want["obs"]) / (np.abs(want["obs"]) + 1e-30)
+    assert rel.max() <= (1e-15 if dtype == torch.float64 else 6e-8), rel.max()   # one rounding to T
+    # a second call finds nothing left to do
+    before = obs.clone()
+    prepare_obs(obs, ty, agents=A)
+    torch.cuda.synchronize()
+    assert torch.equal(before, obs)

@@ -159,12 +159,15 @@ int main(int argc, char** argv)
     const long long A = argc > 1 ? atoll(argv[1]) : 65536;
     const int M = 16, RING = argc > 2 ? atoi(argv[2]) : 10, ITERS = 400;
     const bool tiled = argc > 3 && atoi(argv[3]) != 0;  // upload obs as [A/64][M][2][64][4]
+    const int tmode = argc > 4 ? atoi(argv[4]) : 0;     // slot kinds: 0 = 8 ellipse + 8 cone, 1 all ellipse, 2 all cone, 3 all empty
+    const bool quick = argc > 5 && atoi(argv[5]) != 0;  // G = 4 only
     std::mt19937 rng(1);
     std::uniform_real_distribution<float> U(-1.f, 1.f);
     std::vector<Batch> ring(RING);
     std::vector<float> hs(A * 4), hu(A * 2), ho((size_t)M * 2 * A * 4);
     std::vector<uint8_t> ht(M);
-    for (int m = 0; m < M; ++m) ht[m] = m < 8 ? 0 : 1;
+    for (int m = 0; m < M; ++m) ht[m] = tmode == 0 ? (m < 8 ? 0 : 1) : tmode == 1 ? 0 : tmode == 2 ? 1 : 255;
+    auto is_ell = [&](int m) { return ht[m] == 0 || (ht[m] == 255 && m < 8); };
     for (int b = 0; b < RING; ++b) {
         for (long long a = 0; a < A; ++a) {
             hs[4 * a] = 50 * U(rng); hs[4 * a + 1] = 50 * U(rng); hs[4 * a + 2] = 3.14f * U(rng); hs[4 * a + 3] = 7.5f + 7.5f * U(rng);
@@ -176,7 +179,7 @@ int main(int argc, char** argv)
                 float* o0 = &ho[(((size_t)m * 2 + 0) * A + a) * 4];
                 float* o1 = &ho[(((size_t)m * 2 + 1) * A + a) * 4];
                 o0[0] = hs[4 * a] + rg * cosf(br); o0[1] = hs[4 * a + 1] + rg * sinf(br);
-                if (m < 8) { o0[2] = 11 + 9 * U(rng); o0[3] = 5.5f + 4.5f * U(rng); o1[0] = 3.14f * U(rng); o1[1] = 2 * U(rng); o1[2] = 2 * U(rng); o1[3] = 0; }
+                if (is_ell(m)) { o0[2] = 11 + 9 * U(rng); o0[3] = 5.5f + 4.5f * U(rng); o1[0] = 3.14f * U(rng); o1[1] = 2 * U(rng); o1[2] = 2 * U(rng); o1[3] = 0; }
                 else { o0[2] = 3.14f * U(rng); o0[3] = 2.5f + 2.5f * U(rng); o1[0] = 4.5f + 2 * U(rng); o1[1] = 0; o1[2] = 0; o1[3] = 0; }
             }
         if (tiled) {
@@ -212,9 +215,10 @@ int main(int argc, char** argv)
         k.state = ring[b].state; k.u_ref = ring[b].u_ref; k.obs = ring[b].obs; k.obs_type = ring[b].type;
         k.u_out = ring[b].u_out; k.status = ring[b].status; k.rows_out = nullptr;
     };
-    printf("layout %s  ", tiled ? "tiled" : "planes");
+    printf("layout %s kinds %d  ", tiled ? "tiled" : "planes", tmode);
     printf("A=%lld M=%d ring=%d  algorithmic bytes/launch %.0f\n", A, M, RING, bytes);
     for (int blocks : {256, 512, 1024, 2048, 4096}) {
+        if (quick && blocks != 2048) continue;
         char nm[64];
         snprintf(nm, sizeof nm, "stream U=1 grid %d", blocks);
         report(nm, time_it([&](int b) { hipLaunchKernelGGL(k_stream<1>, dim3(blocks), dim3(256), 0, 0, (const float4*)ring[b].obs, (long long)M * 2 * A, ring[b].u_out); }, ITERS, RING));
@@ -235,11 +239,9 @@ int main(int argc, char** argv)
     report("loadonly G=" #G " no ego, 1 store", time_it([&](int b) { setk(b); hipLaunchKernelGGL((k_loadonly<G, RPL, 4>), dim3((unsigned)((A * G + 255) / 256)), dim3(256), 0, 0, k); }, ITERS, RING)); \
     report("rowsonly G=" #G, time_it([&](int b) { setk(b); hipLaunchKernelGGL((k_rowsonly<G, RPL>), dim3((unsigned)((A * G + 255) / 256)), dim3(256), 0, 0, k); }, ITERS, RING)); \
     report("full     G=" #G, time_it([&](int b) { setk(b); launch_group<float, false, G, RPL>(k, 0); }, ITERS, RING));
-    RUN_G(1, 16)
-    RUN_G(2, 8)
+    if (!quick) { RUN_G(1, 16) RUN_G(2, 8) }
     RUN_G(4, 4)
-    RUN_G(8, 2)
-    RUN_G(16, 1)
+    if (!quick) { RUN_G(8, 2) RUN_G(16, 1) }
     CK(hipDeviceSynchronize());
     int st[8];
     CK(hipMemcpy(st, ring[0].status, sizeof st, hipMemcpyDeviceToHost));
