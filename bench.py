@@ -141,13 +141,19 @@ def _profile_json(name):
         return None
 
 
-def _time_graph(walk, stream, n_per_walk, reps):
-    """us per launch of walk() (n_per_walk launches) replayed from a hipGraph on `stream`."""
+def _time_graph(walk, stream, n_per_walk, reps, graph=True):
+    """ms per launch of walk() (n_per_walk launches) replayed from a hipGraph on `stream` (or launched
+    eagerly, graph=False: a profiler then sees every launch)."""
     walk()
     torch.cuda.synchronize()
-    g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g, stream=stream):
-        walk()
+
+    class _Eager:
+        replay = staticmethod(walk)
+    g = _Eager
+    if graph:
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=stream):
+            walk()
     for _ in range(reps):   # the GPU idled while the host built the batch: let the clocks come back
         g.replay()
     torch.cuda.synchronize()
@@ -160,7 +166,7 @@ def _time_graph(walk, stream, n_per_walk, reps):
     return e0.elapsed_time(e1) / (reps * n_per_walk)   # ms per launch
 
 
-def large_batch(flt, device, layout, slots, agents=1 << 20, n=3, reps=60):
+def large_batch(flt, device, layout, slots, agents=1 << 20, n=3, reps=60, graph=True):
     """The same kernel on 2^20 agents per launch (not part of `value`): at that size a launch is
     no longer dominated by its start-up and tail.  The ring re-uses one C4 batch rotated by whole
     tiles: 3 x 575 MB, more than twice the Infinity Cache."""
@@ -182,7 +188,7 @@ def large_batch(flt, device, layout, slots, agents=1 << 20, n=3, reps=60):
         def walk():
             for b in ring:
                 flt.solve(b["state"], b["u_ref"], b["obs"], ty, u_out=b["u_out"], status=b["status"])
-        ms = _time_graph(walk, st, n, reps)
+        ms = _time_graph(walk, st, n, reps, graph=graph)
     ab = algorithmic_bytes(agents, ROWS)
     return {"agents": agents, "kernel_ms": ms, "solves_per_s": agents / (ms * 1e-3),
             "achieved_GBps": ab / (ms * 1e-3) / 1e9, "frac": ab / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
@@ -326,6 +332,16 @@ def worker(args):
             return 2
 
     A, M = args.agents, ROWS
+    if args.large_only:
+        # the 2^20-agent measurement on its own (what tools/prof_large.sh runs under rocprofv3)
+        from sccav_cbf_amd.batched import BatchedCBF
+        flt = BatchedCBF(alpha=1.0, lr=1.45, lf=1.45, R=np.diag([0.5, 0.5]), lanes_per_qp=args.lanes,
+                         streamed_obs=not args.no_stream_hint)
+        out = large_batch(flt, device, args.layout, args.slots, reps=args.steps if args.steps < 1000 else 60,
+                          graph=not args.no_graph)
+        out["large_only"] = True
+        print(json.dumps(out), flush=True)
+        return 0
     if stub:
         # launcher / collective plumbing rehearsal on the CPU: the "solve" is a copy, nothing is measured
         ring = [dict(u_ref=torch.zeros((A, 2)), u_out=torch.empty((A, 2)),
@@ -522,6 +538,8 @@ def main():
     ap.add_argument("--no-stream-hint", action="store_true",
                     help="do not tell the library that each step's obstacle slots are read once (SCCBF_FLAG_OBS_STREAMED)")
     ap.add_argument("--no-large", action="store_true", help="skip the extra 1M-agent measurement (N=1 only)")
+    ap.add_argument("--large-only", action="store_true",
+                    help="only the 2^20-agent measurement (with --steps < 1000: that many walks over its ring of 3)")
     ap.add_argument("--no-fp64", action="store_true", help="skip the fp64 lines (N=1 only)")
     ap.add_argument("--ramp-ms", type=float, default=60.0,
                     help="untimed work ahead of the warm-up steps that lets an idle GPU reach its clocks")

@@ -90,31 +90,77 @@ __device__ inline void stage_course_(CoursePass<T>& c, const typename VT<T>::v4*
     }
 }
 
+// Squared length of (ex, ey), in ONE fixed sequence of roundings (ey * ey, then a fused multiply-add)
+// for way-points and boxes alike.  With it a box's distance is never above the distance of a
+// way-point inside the box, in floating point as in exact arithmetic: subtraction, square and the
+// fused sum are monotone, so no slack is needed between the two and equal values mean ties.
+template <typename T> __device__ inline T len2_(T ex, T ey)
+{
+#pragma clang fp contract(off)
+    const T ey2 = ey * ey;
+    return __builtin_fma(ex, ex, ey2);
+}
+template <> __device__ inline float len2_<float>(float ex, float ey)
+{
+#pragma clang fp contract(off)
+    const float ey2 = ey * ey;
+    return __builtin_fmaf(ex, ex, ey2);
+}
+
 // Squared distance from (fx, fy) to a bounding box (infinite for the box of an empty run).
 template <typename T> __device__ inline T box_d2_(T x0, T x1, T y0, T y1, T fx, T fy)
 {
     const T dx = max_(max_(x0 - fx, fx - x1), T(0));
     const T dy = max_(max_(y0 - fy, fy - y1), T(0));
-    return dx * dx + dy * dy;
+    return len2_(dx, dy);
+}
+
+// Can a box at squared distance d2 whose way-points start at index i0 still change the answer?
+// lim: least squared distance known, ai: some way-point with an index <= ai lies at that distance
+// (INT_MAX: none known).
+// Ties go to the lowest index, so a box that can only tie behind that index is out (the box that
+// holds it stays in: the answer is taken from the way-points scanned).
+template <typename T> __device__ inline bool box_in_(T d2, int i0, T lim, int ai)
+{
+    return d2 < lim || (d2 == lim && i0 <= ai);
+}
+// fp32: squared distances are not negative, so their bit patterns order as they do, and the pair
+// (distance, index) compares as one 64-bit integer
+__device__ inline unsigned long long dist_key_(float d2, int i)
+{
+    return ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)i;
+}
+template <> __device__ inline bool box_in_<float>(float d2, int i0, float lim, int ai)
+{
+    return dist_key_(d2, i0) <= dist_key_(lim, ai);
+}
+// is (m, i) a better bound than (lim, ai)?
+template <typename T> __device__ inline bool bound_lt_(T m, int i, T lim, int ai)
+{
+    return m < lim || (m == lim && i < ai);
+}
+template <> __device__ inline bool bound_lt_<float>(float m, int i, float lim, int ai)
+{
+    return dist_key_(m, i) < dist_key_(lim, ai);
 }
 
 // Nearest way-point of one staged pass to (fx, fy), by the four lanes of a group.  lim is the
-// best squared distance known so far (on entry: any upper bound of the answer).  First the group
-// lists the runs that can hold the answer: the outer boxes not farther than lim (four per lane and
-// step), then the run boxes inside those (one per lane and outer box); then it scans the listed
-// runs in index order, eight way-points per lane, tightening lim as it goes and skipping a run
-// whose box has fallen behind the bound.  best / bi: this lane's nearest way-point so far (strict
-// "<" in index order, so the first index wins a tie).  Every group works through its own list and
-// the groups of a wavefront scan their k-th runs together: a wavefront pays for the longest list
-// among its groups, not for their union.
+// best squared distance known so far (on entry: any upper bound of the answer) and ai an index at or
+// below which a way-point is known to lie at that distance (INT_MAX if none is known).  First the group lists the runs that can hold
+// the answer: the outer boxes that can still change it (four per lane and step), then the run boxes
+// inside those (one per lane and outer box); then it scans the listed runs in index order, eight
+// way-points per lane, tightening lim as it goes and skipping runs that have fallen behind the
+// bound.  An agent so far from the course that every way-point lies at the same computed distance
+// scans one run: every other box can only tie with a higher index and fails its test.
+// best / bi: this lane's nearest way-point so far (strict "<" in index order, so the first index
+// wins a tie).  Every group works through its own list and the groups of a wavefront scan their
+// k-th runs together: a wavefront pays for the longest list among its groups, not for their union.
 template <typename T>
 __device__ inline void nearest_in_pass_(const CoursePass<T>& c, T fx, T fy, int g, int base, int runs,
-                                        T& lim, T& best, int& bi)
+                                        T& lim, int& ai, T& best, int& bi)
 {
     constexpr int G = kNomLanes;
     static_assert(kSup == G && kSups <= 32 && kSubs <= 64, "one run box per lane inside an outer box; masks");
-    // (a few ulps of slack: the box distance and the way-point distance round independently)
-    constexpr T kSlack = T(1) + T(8) * Lim<T>::eps;
     const int sups = (runs + kSup - 1) / kSup;
     // Every outer box holds a way-point, so the answer is no farther than the far corner of any of
     // them: for an agent that has left the course far behind (its last target says nothing any
@@ -128,35 +174,39 @@ __device__ inline void nearest_in_pass_(const CoursePass<T>& c, T fx, T fy, int 
         const T X0 = c.X0[so], X1 = c.X1[so], Y0 = c.Y0[so], Y1 = c.Y1[so];
         d2s[i] = so < sups ? box_d2_(X0, X1, Y0, Y1, fx, fy) : T(INFINITY);
         const T ex = max_(fx - X0, X1 - fx), ey = max_(fy - Y0, Y1 - fy);
-        far = min_(far, so < sups ? ex * ex + ey * ey : T(INFINITY));
+        far = min_(far, so < sups ? len2_(ex, ey) : T(INFINITY));
     }
     far = min_(far, __shfl_xor(far, 1, 64));
     far = min_(far, __shfl_xor(far, 2, 64));
-    lim = min_(lim, far * kSlack);
+    ai = far < lim ? 0x7fffffff : ai;  // some way-point lies within `far`, which one is not known
+    lim = min_(lim, far);
     unsigned smask = 0u;
 #pragma unroll
-    for (int i = 0; i < kMine; ++i) smask |= d2s[i] <= lim * kSlack ? 1u << (i * G + g) : 0u;
+    for (int i = 0; i < kMine; ++i)
+        smask |= box_in_(d2s[i], base + (i * G + g) * kSup * kSub, lim, ai) ? 1u << (i * G + g) : 0u;
     smask = group_or<G>(smask);
     unsigned rlo = 0u, rhi = 0u;  // bit r: run r is listed
     while (smask != 0u) {
         const int rr = (__ffs(smask) - 1) * kSup + g;
         smask &= smask - 1u;
-        const bool in = box_d2_(c.x0[rr], c.x1[rr], c.y0[rr], c.y1[rr], fx, fy) <= lim * kSlack;
+        const bool in = box_in_(box_d2_(c.x0[rr], c.x1[rr], c.y0[rr], c.y1[rr], fx, fy), base + rr * kSub, lim, ai);
         rlo |= (in && rr < 32) ? 1u << rr : 0u;
         rhi |= (in && rr >= 32) ? 1u << (rr - 32) : 0u;
     }
     unsigned long long rmask = ((unsigned long long)group_or<G>(rhi) << 32) | group_or<G>(rlo);
-    const T listed = lim;  // rmask and lim are the same in the four lanes of a group
+    const T listed = lim;  // rmask, lim and ai are the same in the four lanes of a group
+    const int listed_ai = ai;
     while (rmask != 0ull) {
         const int r = __ffsll((long long)rmask) - 1;
         rmask &= rmask - 1ull;
-        // the bound may have tightened since the boxes were tested
-        if (lim < listed && !(box_d2_(c.x0[r], c.x1[r], c.y0[r], c.y1[r], fx, fy) <= lim * kSlack)) continue;
+        // the bound may have moved since the boxes were tested
+        if ((lim < listed || ai < listed_ai) &&
+            !box_in_(box_d2_(c.x0[r], c.x1[r], c.y0[r], c.y1[r], fx, fy), base + r * kSub, lim, ai))
+            continue;
 #pragma unroll
         for (int j = 0; j < kSub / G; ++j) {  // lane g: way-points 8 g .. 8 g + 7 of the run
             const int jj = g * (kSub / G) + j;
-            const T ex = fx - c.x[r * kSubStride + jj], ey = fy - c.y[r * kSubStride + jj];
-            const T d = ex * ex + ey * ey;
+            const T d = len2_(fx - c.x[r * kSubStride + jj], fy - c.y[r * kSubStride + jj]);
             const bool lt = d < best;
             best = lt ? d : best;
             bi = lt ? base + r * kSub + jj : bi;
@@ -165,7 +215,13 @@ __device__ inline void nearest_in_pass_(const CoursePass<T>& c, T fx, T fy, int 
         T m = best;
         m = min_(m, __shfl_xor(m, 1, 64));
         m = min_(m, __shfl_xor(m, 2, 64));
-        lim = min_(lim, m);
+        // Runs are scanned in index order and every scanned run that reached the bound has pulled ai
+        // down to its own end, so a way-point at distance m <= lim with the end of this run below ai
+        // lies in this run: its end bounds the index of a way-point at the new lim.
+        const int rend = base + r * kSub + kSub - 1;
+        const bool upd = bound_lt_(m, rend, lim, ai);
+        lim = upd ? m : lim;
+        ai = upd ? rend : ai;
     }
 }
 
@@ -228,9 +284,10 @@ __global__ __launch_bounds__(kNomBlock) void k_nominal(const NArgs<T> p)
     const int last = p.target_idx[a];
     // upper bound of the answer: the distance to the way-point targeted last tick
     T lim;
+    int ai = min(max(last, 0), p.N - 1);  // a way-point known to lie at distance lim
     {
-        const v2 wl = *reinterpret_cast<const v2*>(traj4 + min(max(last, 0), p.N - 1));
-        lim = (fx - wl.x) * (fx - wl.x) + (fy - wl.y) * (fy - wl.y);
+        const v2 wl = *reinterpret_cast<const v2*>(traj4 + ai);
+        lim = len2_(fx - wl.x, fy - wl.y);
     }
     T best = INFINITY;
     int bi = 0x7fffffff;
@@ -239,7 +296,7 @@ __global__ __launch_bounds__(kNomBlock) void k_nominal(const NArgs<T> p)
         __syncthreads();
         stage_course_<T, kNomBlock>(c, traj4, base, n);
         __syncthreads();
-        nearest_in_pass_(c, fx, fy, g, base, (n + kSub - 1) / kSub, lim, best, bi);
+        nearest_in_pass_(c, fx, fy, g, base, (n + kSub - 1) / kSub, lim, ai, best, bi);
     }
     bi = group_nearest_(best, bi, p.N);
     const v4 wn = traj4[bi];
@@ -403,10 +460,11 @@ void k_rollout(const RArgs<T> a)
         const T fx = st.x + np.axle * cth, fy = st.y + np.axle * sth;
         const int lt = min(max(tgt, 0), np.N - 1);
         const T lx = c.x[(lt / kSub) * kSubStride + lt % kSub], ly = c.y[(lt / kSub) * kSubStride + lt % kSub];
-        T lim = (fx - lx) * (fx - lx) + (fy - ly) * (fy - ly);
+        T lim = len2_(fx - lx, fy - ly);
+        int ai = lt;
         T best = INFINITY;
         int bi = 0x7fffffff;
-        nearest_in_pass_(c, fx, fy, g, 0, runs, lim, best, bi);
+        nearest_in_pass_(c, fx, fy, g, 0, runs, lim, ai, best, bi);
         bi = group_nearest_(best, bi, np.N);
         tgt = tgt >= bi ? tgt : bi;
         const int ti = min(tgt, np.N - 1);

@@ -465,3 +465,52 @@ def test_solve_step_is_solve_then_vehicle_step(dtype, lanes, M, tiled):
     assert ((s1[fin] - s0[fin]).abs() / scale).max() <= tol
     assert (b1[fin] - b0[fin]).abs().max() <= tol
     assert not torch.equal(s1, state)
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
+def test_nearest_waypoint_of_agents_far_off_the_course(dtype):
+    """Agents thrown 1e3 ... 1e12 m off the course: in the working precision more and more way-points
+    lie at the same computed distance, down to all of them.  The answer is still the first index of
+    the least computed squared distance fma(ex, ex, ey * ey), and the search must not fall back to
+    scanning the whole course for it (that is a matter of time, measured elsewhere; here: the index)."""
+    from sccav_cbf_amd.nominal import BatchedNominal
+    npdt = np.float64 if dtype == torch.float64 else np.float32
+    traj = _course().astype(npdt)
+    N = traj.shape[0]
+    rng = np.random.default_rng(11)
+    A = 4096
+    mag = 10.0 ** rng.uniform(3, 12, A)
+    ang = rng.uniform(0, 2 * np.pi, A)
+    state = np.zeros((A, 4), dtype=npdt)
+    state[:, 0] = (50 + mag * np.cos(ang)).astype(npdt)
+    state[:, 1] = (-10 + mag * np.sin(ang)).astype(npdt)
+    state[:, 3] = 5.0
+    last = rng.integers(0, N, A).astype(np.int32)
+    last[::3] = 0
+    nom = BatchedNominal(axle=0.0)          # front axle = reference point: fx = x exactly
+    tgt = torch.from_numpy(last.copy()).to(DEV)
+    nom.control(torch.from_numpy(state).to(DEV), torch.from_numpy(traj).to(DEV), tgt)
+    torch.cuda.synchronize()
+    got = tgt.cpu().numpy()
+    # the same roundings on the host: ex, ey in the working precision, ey * ey rounded, then one fused sum
+    ex = (state[:, None, 0] - traj[None, :, 0]).astype(npdt).astype(np.float64)
+    ey = (state[:, None, 1] - traj[None, :, 1]).astype(npdt).astype(np.float64)
+    ey2 = (ey * ey).astype(npdt).astype(np.float64)
+    if dtype == torch.float32:
+        d = (ex * ex + ey2).astype(npdt)            # 48 + 24 bits: exact in float64 but for rare double roundings
+    else:
+        import math
+        d = np.empty_like(ex)
+        fma = getattr(math, "fma", None)
+        for i in range(A):                          # float64: no wider type to hide the fused rounding in
+            d[i] = [fma(a, a, b) for a, b in zip(ex[i], ey2[i])] if fma else ex[i] * ex[i] + ey2[i]
+    nearest = d.argmin(axis=1)                      # first index of the least value
+    want = np.maximum(last, nearest)                # the target index never moves backwards
+    ok = got == want
+    tie = d[np.arange(A), np.minimum(got, N - 1)] == d.min(axis=1)
+    if dtype == torch.float32:
+        assert ok.mean() >= 0.999 and (ok | tie).all()
+    else:
+        # Python 3.10 has no math.fma: the unfused sum may differ in the last bit, which can reorder exact-looking ties
+        assert ok.mean() >= 0.98 and (ok | (np.abs(d[np.arange(A), np.minimum(got, N - 1)] - d.min(axis=1))
+                                            <= 4e-16 * d.min(axis=1))).all()
