@@ -106,8 +106,7 @@ extern "C" {
 #define SCCBF_OK 0
 #define SCCBF_ERR_ARG (-1)         /* NULL pointer / negative size / A >= 2^31 / bad enum or flags */
 #define SCCBF_ERR_ROWS (-2)        /* M above SCCBF_MAX_ROWS, or above the limit stated at the entry point
-                                      (256 rows for the DUM / SADBM models, 64 slots and 2048 way-points
-                                      for the rollout) */
+                                      (256 rows for the DUM / SADBM models, 64 slots for the rollout) */
 #define SCCBF_ERR_WEIGHT (-3)      /* R not symmetric positive definite */
 #define SCCBF_ERR_LAUNCH (-4)      /* hipLaunch failed */
 #define SCCBF_ERR_VARIANT (-5)     /* lanes_per_qp cannot hold M rows */
@@ -275,6 +274,25 @@ int sccbf_vehicle_step_f64(int64_t A, double* state, const double* u, double lr,
                            double max_steer, double dt, double* beta_out, void* stream);
 
 /*
+ * The kinematic steps of the reference drivers' State class, for the models whose input is not
+ * (a, delta) of the dynamic bicycle; in place on state T[A][4], u T[A][2]:
+ *   SCCBF_STEP_KIN_ACC   State.update, test_scripts/stanley_controller_ellipse.py:86-100: u = (a, delta),
+ *                        x += v cos(yaw) dt, y += v sin(yaw) dt, yaw += v / L tan(delta) dt (normalised to
+ *                        [-pi, pi], cbf/utils.py:93-106), v += a dt; delta clipped to +-max_steer
+ *   SCCBF_STEP_KIN_VEL   State.update_by_vel, 102-118: u = (v, delta), the same with v = u[0] at the end
+ *                        (what the drivers apply to KBM_VC_CBF2D's answer, 702-714)
+ *   SCCBF_STEP_UNICYCLE  u = (a, omega): x, y as above, yaw += omega dt, v += a dt: the Euler step of the
+ *                        model DUM_CBF_2DS filters (cbf/cbf.py:237-245); the reference ships no driver for it
+ */
+#define SCCBF_STEP_KIN_ACC 0
+#define SCCBF_STEP_KIN_VEL 1
+#define SCCBF_STEP_UNICYCLE 2
+int sccbf_vehicle_step_kin_f32(int64_t A, float* state, const float* u, int32_t mode, double L,
+                               double max_steer, double dt, void* stream);
+int sccbf_vehicle_step_kin_f64(int64_t A, double* state, const double* u, int32_t mode, double L,
+                               double max_steer, double dt, void* stream);
+
+/*
  * One control tick's filter and vehicle step in one launch: sccbf_solve_* (reference
  * cbf/cbf.py:166-220) and then sccbf_vehicle_step_* (State.update_com, reference
  * test_scripts/stanley_controller_ellipse.py:122-131, called with the filtered input right after
@@ -295,11 +313,23 @@ int sccbf_solve_step_f64(const sccbf_params* p, double max_steer, double dt, int
 
 /*
  * Closed-loop rollout: `ticks` control ticks of
- *     nominal input (sccbf_nominal_*) -> filter (sccbf_solve_*, DBM) -> vehicle step
- *     (sccbf_vehicle_step_*) -> obstacle motion
+ *     nominal input (sccbf_nominal_*) -> filter (sccbf_solve_* / sccbf_solve_sa_*) -> vehicle step
+ *     -> obstacle motion
  * for every agent in one launch; the main loop of the reference drivers
  * (test_scripts/stanley_controller_ellipse.py:630-760) for a whole batch.  Tick by tick
- * the results are those of the three entry points called in turn.
+ * the results are those of the entry points called in turn.  By p->dynamics:
+ *   SCCBF_DYN_DBM    u_ref = (a_ref, delta_ref); step sccbf_vehicle_step_* (update_com, 122-131), as the
+ *                    drivers do after DBM_CBF_2DS.solve_cbf (760-769)
+ *   SCCBF_DYN_KBM    u_ref = (v, delta_ref) with v the tracked speed (target_speed or the way-point's,
+ *                    633); step SCCBF_STEP_KIN_VEL (update_by_vel, 102-118), as after
+ *                    KBM_VC_CBF2D.solve_cbf (702-714); pid_state is carried but does not enter u_ref
+ *   SCCBF_DYN_DUM    u_ref = (a_ref, v tan(delta_ref) / L), the yaw rate of the nominal steering (the
+ *                    relation of cbf/cbf.py:75); step SCCBF_STEP_UNICYCLE.  The reference ships no
+ *                    driver for this model: the loop is this library's
+ *   SCCBF_DYN_SADBM  sccbf_solve_sa_* with dt = the tick length and SCCBF_FLAG_CONE_BETA_STATE (every
+ *                    cone takes the agent's slip angle, cbf/cbf.py:424-427), slip carried in `slip`;
+ *                    step update_com with the filter's (a, delta), as the drivers' commented-out
+ *                    SADBM lines would (734, 807)
  */
 #define SCCBF_MOTION_STATIC 0            /* obstacle slots stay where they are */
 #define SCCBF_MOTION_CONSTANT_VELOCITY 1 /* per tick: ellipse centre += (vx, vy) dt; cone centre
@@ -328,29 +358,35 @@ void sccbf_default_rollout_params(sccbf_rollout_params* p);
 
 /*
  *   state        T[A][4]   in: initial states; out: states after the last tick
- *   traj         T[N][4]   course, 1 <= N <= 2048 way-points (SCCBF_ERR_ROWS beyond).  N = 0
+ *   traj         T[N][4]   course, N >= 1 way-points: up to 2048 stay in LDS for the whole launch, a longer
+ *                          course is staged pass by pass on every tick (slower).  N = 0
  *                          (traj, target_idx, pid_state then unused, may be NULL): no course, the
  *                          nominal input is (0, 0) on every tick, as for the stationary ego of
  *                          radial_dynamic_obstacles.py:444
  *   target_idx   i32[A]    in/out, as in sccbf_nominal_*
  *   pid_state    T[A][2]   in/out or NULL, as in sccbf_nominal_*
+ *   slip         T[A][2]   in/out, SCCBF_DYN_SADBM only (else unused, may be NULL): beta, beta_ref_last
+ *                          as in sccbf_solve_sa_*
  *   obs, obs_type          as in sccbf_solve_* (planes or tiles; not the shared table), 1 <= M <= 64;
  *                          read once: moving obstacles advance in registers, obs is not written
  *   h_min        T[A]      optional: least barrier value over all ticks and slots
  *   n_active     i32[A]    optional: ticks on which the filter changed the nominal input
  *   n_infeasible i32[A]    optional: ticks with SCCBF_STATUS_INFEASIBLE
- *   trace        T[ticks][A][4] optional: per tick a*, delta*, slip angle beta of the step, status
+ *   trace        T[ticks][A][4] optional: per tick the filter's answer u[0], u[1] (in the model's input
+ *                          coordinates, as u_out of the solve entry), the slip angle beta of an update_com
+ *                          step (0 for the other steps), status
+ * p->flags: the layout flags only (SCCBF_FLAG_SLIP_IO, SCCBF_FLAG_CONE_BETA_STATE: SCCBF_ERR_ARG).
  */
 int sccbf_rollout_f32(const sccbf_params* p, const sccbf_nominal_params* np,
                       const sccbf_rollout_params* rp, int64_t A, int32_t M, int32_t N,
                       float* state, const float* traj, int32_t* target_idx, float* pid_state,
-                      const float* obs, const uint8_t* obs_type,
+                      float* slip, const float* obs, const uint8_t* obs_type,
                       float* h_min, int32_t* n_active, int32_t* n_infeasible, float* trace,
                       void* stream);
 int sccbf_rollout_f64(const sccbf_params* p, const sccbf_nominal_params* np,
                       const sccbf_rollout_params* rp, int64_t A, int32_t M, int32_t N,
                       double* state, const double* traj, int32_t* target_idx, double* pid_state,
-                      const double* obs, const uint8_t* obs_type,
+                      double* slip, const double* obs, const uint8_t* obs_type,
                       double* h_min, int32_t* n_active, int32_t* n_infeasible, double* trace,
                       void* stream);
 

@@ -232,6 +232,33 @@ def vehicle_step_batch(state, u, lr, lf, max_steer, dt):
     return beta
 
 
+def normalize_angle(a):
+    """cbf/utils.py:93-106: add / subtract 2 pi until the angle lies in [-pi, pi]."""
+    a = np.array(a, dtype=np.float64)
+    a -= 2 * np.pi * np.rint(a / (2 * np.pi))
+    a = np.where(a > np.pi, a - 2 * np.pi, a)
+    return np.where(a < -np.pi, a + 2 * np.pi, a)
+
+
+def vehicle_step_kin_batch(state, u, mode, L, max_steer, dt):
+    """In place on state (A,4) float64: State.update (mode "acc", u = (a, delta)) and
+    State.update_by_vel ("vel", u = (v, delta)) of reference
+    test_scripts/stanley_controller_ellipse.py:86-118, and the Euler step of the unicycle that
+    DUM_CBF_2DS filters ("unicycle", u = (a, omega), cbf/cbf.py:237-245)."""
+    assert state.dtype == np.float64
+    u = _f64(u)
+    x, y, yaw, v = (state[:, i].copy() for i in range(4))
+    state[:, 0] = x + v * np.cos(yaw) * dt
+    state[:, 1] = y + v * np.sin(yaw) * dt
+    if mode == "unicycle":
+        state[:, 2] = yaw + u[:, 1] * dt
+        state[:, 3] = v + u[:, 0] * dt
+        return
+    delta = np.clip(u[:, 1], -max_steer, max_steer)
+    state[:, 2] = normalize_angle(yaw + v / L * np.tan(delta) * dt)
+    state[:, 3] = u[:, 0] if mode == "vel" else v + u[:, 0] * dt
+
+
 def seeker_step(obs, obs_type, ego_xy, dt, k=0.2, v_min=3.0):
     """ObstacleSpawner.update_seekers, reference test_scripts/radial_dynamic_obstacles.py:210-234,
     for every ellipse and radial slot of obs (M,2,A,4) float64, in place, in the reference's order:

@@ -27,8 +27,10 @@ EXPORTS = ("sccbf_version", "sccbf_strerror", "sccbf_default_params", "sccbf_sol
            "sccbf_default_rollout_params", "sccbf_rollout_f32", "sccbf_rollout_f64",
            "sccbf_solve_sa_f32", "sccbf_solve_sa_f64", "sccbf_ingest_bbox_f32", "sccbf_ingest_bbox_f64",
            "sccbf_lane_fit_f32", "sccbf_lane_fit_f64", "sccbf_solve_step_f32", "sccbf_solve_step_f64",
-           "sccbf_prepare_obs_f32", "sccbf_prepare_obs_f64")
+           "sccbf_prepare_obs_f32", "sccbf_prepare_obs_f64", "sccbf_vehicle_step_kin_f32",
+           "sccbf_vehicle_step_kin_f64")
 MOTION_STATIC, MOTION_CONSTANT_VELOCITY, MOTION_SEEKER = 0, 1, 2
+STEP_KIN_ACC, STEP_KIN_VEL, STEP_UNICYCLE = 0, 1, 2
 NOMINAL_WAYPOINT_SPEED = 1
 
 
@@ -133,7 +135,11 @@ def load():
         f = getattr(L, name)
         f.restype = C.c_int
         f.argtypes = [C.POINTER(Params), C.POINTER(NominalParams), C.POINTER(RolloutParams), C.c_int64,
-                      C.c_int32, C.c_int32] + [vp] * 11
+                      C.c_int32, C.c_int32] + [vp] * 12
+    for name in ("sccbf_vehicle_step_kin_f32", "sccbf_vehicle_step_kin_f64"):
+        f = getattr(L, name)
+        f.restype = C.c_int
+        f.argtypes = [C.c_int64, vp, vp, C.c_int32, C.c_double, C.c_double, C.c_double, vp]
     _lib = L
     return L
 

@@ -340,36 +340,40 @@ int vehicle_step_impl(int64_t A, T* state, const T* u, double lr, double lf, dou
 }
 
 template <typename T, int RPL>
-int launch_rollout(const RArgs<T>& r, hipStream_t s)
+int launch_rollout(const RArgs<T>& r, bool ext, hipStream_t s)
 {
     const long long per_block = kBlock / kNomLanes;
     const long long blocks = (r.f.A + per_block - 1) / per_block;
     if (blocks > 0x7fffffffLL) return SCCBF_ERR_ARG;
-    hipLaunchKernelGGL((k_rollout<T, RPL>), dim3((unsigned)blocks), dim3(kBlock), 0, s, r);
+    if (ext) hipLaunchKernelGGL((k_rollout<T, RPL, true>), dim3((unsigned)blocks), dim3(kBlock), 0, s, r);
+    else hipLaunchKernelGGL((k_rollout<T, RPL, false>), dim3((unsigned)blocks), dim3(kBlock), 0, s, r);
     return hipGetLastError() == hipSuccess ? SCCBF_OK : SCCBF_ERR_LAUNCH;
 }
 
 template <typename T>
 int rollout_impl(const sccbf_params* sp, const sccbf_nominal_params* np, const sccbf_rollout_params* rp,
                  int64_t A, int32_t M, int32_t N, T* state, const T* traj, int32_t* target_idx, T* pid_state,
-                 const T* obs, const uint8_t* obs_type, T* h_min, int32_t* n_active, int32_t* n_infeasible,
-                 T* trace, void* stream)
+                 T* slip, const T* obs, const uint8_t* obs_type, T* h_min, int32_t* n_active,
+                 int32_t* n_infeasible, T* trace, void* stream)
 {
     if (!np || !rp) return SCCBF_ERR_ARG;
     RArgs<T> r;
     int rc = fill_args<T>(sp, A, M, r.f);
     if (rc != SCCBF_OK) return rc;
-    if (N > kTrajChunk || M > 16 * kNomLanes) return SCCBF_ERR_ROWS;
+    if (M > 16 * kNomLanes) return SCCBF_ERR_ROWS;
     if (N < 0 || M < 1 || rp->ticks < 0 || !(rp->dt > 0.0) || !(rp->max_steer >= 0.0)) return SCCBF_ERR_ARG;
     if (rp->motion != SCCBF_MOTION_STATIC && rp->motion != SCCBF_MOTION_CONSTANT_VELOCITY &&
         rp->motion != SCCBF_MOTION_SEEKER)
         return SCCBF_ERR_ARG;
     if (rp->motion == SCCBF_MOTION_SEEKER && !(rp->seek_gain >= 0.0 && rp->seek_v_min >= 0.0)) return SCCBF_ERR_ARG;
-    if (sp->dynamics != SCCBF_DYN_DBM) return SCCBF_ERR_ARG;  // update_com is the DBM step
+    if (sp->flags & (SCCBF_FLAG_SLIP_IO | SCCBF_FLAG_CONE_BETA_STATE)) return SCCBF_ERR_ARG;  // works in the caller's coordinates
     if (sp->flags & SCCBF_FLAG_OBS_SHARED) return SCCBF_ERR_ARG;  // moving obstacles are per agent
+    const bool sadbm = sp->dynamics == SCCBF_DYN_SADBM;
+    if ((sp->dynamics == SCCBF_DYN_KBM || sp->dynamics == SCCBF_DYN_DUM) && !(sp->L > 0.0)) return SCCBF_ERR_ARG;
     if (A == 0 || rp->ticks == 0) return SCCBF_OK;
     if (!state || !obs || !obs_type) return SCCBF_ERR_ARG;
     if (N > 0 && (!traj || !target_idx)) return SCCBF_ERR_ARG;
+    if (sadbm && !slip) return SCCBF_ERR_ARG;
     if (N == 0) pid_state = nullptr;
     if (pid_state && !(np->dt > 0.0)) return SCCBF_ERR_ARG;
     fill_nominal_args<T>(np, A, N, r.n);
@@ -378,18 +382,36 @@ int rollout_impl(const sccbf_params* sp, const sccbf_nominal_params* np, const s
     r.n.state = state; r.n.traj = traj; r.n.target_idx = target_idx; r.n.pid_state = pid_state;
     r.n.u_ref = nullptr;
     r.state = state;
+    r.slip = sadbm ? slip : nullptr;
     r.k_in = (T)(sp->lr / (sp->lf + sp->lr)); r.inv_lr = (T)(1.0 / sp->lr);
-    r.max_steer = (T)rp->max_steer; r.dt = (T)rp->dt;
+    r.max_steer = (T)rp->max_steer; r.dt = (T)rp->dt; r.inv_dt = (T)(1.0 / rp->dt);
     r.seek_gain = (T)rp->seek_gain; r.seek_v_min = (T)rp->seek_v_min;
     r.ticks = rp->ticks; r.motion = rp->motion;
     r.h_min = h_min; r.n_active = n_active; r.n_infeasible = n_infeasible; r.trace = trace;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const bool ext = sadbm || sp->dynamics == SCCBF_DYN_DUM;
     const int rpl = (M + kNomLanes - 1) / kNomLanes;
-    if (rpl <= 1) return launch_rollout<T, 1>(r, s);
-    if (rpl <= 2) return launch_rollout<T, 2>(r, s);
-    if (rpl <= 4) return launch_rollout<T, 4>(r, s);
-    if (rpl <= 8) return launch_rollout<T, 8>(r, s);
-    return launch_rollout<T, 16>(r, s);
+    if (rpl <= 1) return launch_rollout<T, 1>(r, ext, s);
+    if (rpl <= 2) return launch_rollout<T, 2>(r, ext, s);
+    if (rpl <= 4) return launch_rollout<T, 4>(r, ext, s);
+    if (rpl <= 8) return launch_rollout<T, 8>(r, ext, s);
+    return launch_rollout<T, 16>(r, ext, s);
+}
+
+template <typename T>
+int vehicle_step_kin_impl(int64_t A, T* state, const T* u, int32_t mode, double L, double max_steer, double dt,
+                          void* stream)
+{
+    if (A < 0 || A > 0x7fffffffLL || !(max_steer >= 0.0) || !std::isfinite(dt)) return SCCBF_ERR_ARG;
+    if (mode != SCCBF_STEP_KIN_ACC && mode != SCCBF_STEP_KIN_VEL && mode != SCCBF_STEP_UNICYCLE) return SCCBF_ERR_ARG;
+    if (mode != SCCBF_STEP_UNICYCLE && !(L > 0.0)) return SCCBF_ERR_ARG;
+    if (A == 0) return SCCBF_OK;
+    if (!state || !u) return SCCBF_ERR_ARG;
+    const long long blocks = (A + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL((k_vehicle_step_kin<T>), dim3((unsigned)blocks), dim3(kBlock), 0,
+                       reinterpret_cast<hipStream_t>(stream), (long long)A, state, u, (int)mode,
+                       (T)(L > 0.0 ? 1.0 / L : 0.0), (T)max_steer, (T)dt);
+    return hipGetLastError() == hipSuccess ? SCCBF_OK : SCCBF_ERR_LAUNCH;
 }
 
 template <typename T>
@@ -706,21 +728,37 @@ void sccbf_default_rollout_params(sccbf_rollout_params* p)
 #ifndef SCCBF_ONLY_F64
 int sccbf_rollout_f32(const sccbf_params* p, const sccbf_nominal_params* np, const sccbf_rollout_params* rp,
                       int64_t A, int32_t M, int32_t N, float* state, const float* traj, int32_t* target_idx,
-                      float* pid_state, const float* obs, const uint8_t* obs_type, float* h_min,
+                      float* pid_state, float* slip, const float* obs, const uint8_t* obs_type, float* h_min,
                       int32_t* n_active, int32_t* n_infeasible, float* trace, void* stream)
 {
-    return rollout_impl<float>(p, np, rp, A, M, N, state, traj, target_idx, pid_state, obs, obs_type, h_min,
+    return rollout_impl<float>(p, np, rp, A, M, N, state, traj, target_idx, pid_state, slip, obs, obs_type, h_min,
                                n_active, n_infeasible, trace, stream);
+}
+#endif
+
+#ifndef SCCBF_ONLY_F64
+int sccbf_vehicle_step_kin_f32(int64_t A, float* state, const float* u, int32_t mode, double L, double max_steer,
+                               double dt, void* stream)
+{
+    return vehicle_step_kin_impl<float>(A, state, u, mode, L, max_steer, dt, stream);
+}
+#endif
+
+#ifndef SCCBF_ONLY_F32
+int sccbf_vehicle_step_kin_f64(int64_t A, double* state, const double* u, int32_t mode, double L, double max_steer,
+                               double dt, void* stream)
+{
+    return vehicle_step_kin_impl<double>(A, state, u, mode, L, max_steer, dt, stream);
 }
 #endif
 
 #ifndef SCCBF_ONLY_F32
 int sccbf_rollout_f64(const sccbf_params* p, const sccbf_nominal_params* np, const sccbf_rollout_params* rp,
                       int64_t A, int32_t M, int32_t N, double* state, const double* traj, int32_t* target_idx,
-                      double* pid_state, const double* obs, const uint8_t* obs_type, double* h_min,
+                      double* pid_state, double* slip, const double* obs, const uint8_t* obs_type, double* h_min,
                       int32_t* n_active, int32_t* n_infeasible, double* trace, void* stream)
 {
-    return rollout_impl<double>(p, np, rp, A, M, N, state, traj, target_idx, pid_state, obs, obs_type, h_min,
+    return rollout_impl<double>(p, np, rp, A, M, N, state, traj, target_idx, pid_state, slip, obs, obs_type, h_min,
                                 n_active, n_infeasible, trace, stream);
 }
 #endif

@@ -1,7 +1,7 @@
 // sccbf_loop.hip.h - nominal controller, vehicle step and the closed-loop rollout kernel
 // Part of the sccbf library (one translation unit, see sccbf.hip); device code for gfx950.
 #pragma once
-#include "sccbf_filter.hip.h"
+#include "sccbf_ext.hip.h"
 
 namespace {
 
@@ -30,11 +30,7 @@ constexpr int kNomBlock = 1024;       // threads per workgroup of the nominal ke
 template <typename T> __device__ inline T wrap_pi_(T a)
 {
     // reference cbf/utils.py:93-106 subtracts / adds 2 pi until the angle is in [-pi, pi]
-    constexpr T kPi = T(3.14159265358979323846), k2Pi = T(6.28318530717958647692);
-    a -= k2Pi * rint(a * (T(1) / k2Pi));
-    a = a > kPi ? a - k2Pi : a;
-    a = a < -kPi ? a + k2Pi : a;
-    return a;
+    return wrap_angle_(a);
 }
 
 // One pass (up to 2048 way-points) of the course in LDS: coordinates in runs of 32, the
@@ -242,7 +238,8 @@ template <typename T> __device__ inline int group_nearest_(T best, int bi, int N
 // Reference cbf/controllers.py:96-99, 118-119, 141-147, 173-180.
 template <typename T>
 __device__ inline void stanley_pid_(const NArgs<T>& p, T yaw, T v, T sth, T cth, T fx, T fy, T xn, T yn,
-                                    T yaw_des, T v_des, bool pid, typename VT<T>::v2& ps, T& acc, T& delta)
+                                    T yaw_des, T v_des, bool pid, typename VT<T>::v2& ps, T& acc, T& delta,
+                                    T* v_track = nullptr)
 {
     // cross-track error projected on the axle direction (-cos(yaw + pi/2), -sin(yaw + pi/2)) = (sin yaw, -cos yaw)
     const T err = (fx - xn) * sth - (fy - yn) * cth;
@@ -250,6 +247,7 @@ __device__ inline void stanley_pid_(const NArgs<T>& p, T yaw, T v, T sth, T cth,
     const T theta_d = atan2_(p.k * err, v + p.ks);
     delta = theta_e + theta_d;
     const T vt = (p.flags & SCCBF_NOMINAL_WAYPOINT_SPEED) ? v_des : p.target_speed;
+    if (v_track) *v_track = vt;
     const T e = vt - v;
     acc = p.kp * e;
     if (pid) {
@@ -329,13 +327,28 @@ __global__ __launch_bounds__(kBlock) void k_vehicle_step(long long A, T* state, 
     if (beta_out) beta_out[a] = beta;
 }
 
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_vehicle_step_kin(long long A, T* state, const T* u, int mode, T inv_L,
+                                                             T max_steer, T dt)
+{
+    using v4 = typename VT<T>::v4;
+    using v2 = typename VT<T>::v2;
+    const long long a = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (a >= A) return;
+    v4 s = reinterpret_cast<v4*>(state)[a];
+    const v2 in = reinterpret_cast<const v2*>(u)[a];
+    kin_step_<T>(s, mode, in.x, in.y, inv_L, max_steer, dt);
+    reinterpret_cast<v4*>(state)[a] = s;
+}
+
 // ---------------------------------------------------- closed-loop rollout in one launch
 template <typename T> struct RArgs {
     KArgs<T> f;   // filter: parameters, obs, obs_type, M, flags (state / u_ref / u_out / status unused)
     NArgs<T> n;   // nominal: parameters, traj, N, target_idx (in/out), pid_state (in/out)
     T* state;     // [A][4] in/out
-    T k_in, inv_lr, max_steer, dt;
+    T k_in, inv_lr, max_steer, dt, inv_dt;
     T seek_gain, seek_v_min;
+    T* slip;      // [A][2] in/out, SADBM only: beta, beta_ref_last
     int ticks;
     int motion;   // SCCBF_MOTION_*
     T* h_min;     // [A] optional
@@ -404,11 +417,17 @@ __device__ inline void seek_slot_(int type, typename VT<T>::v4& oa, typename VT<
 
 // `ticks` control ticks of nominal controller -> filter -> vehicle step (-> obstacle motion)
 // for every agent in ONE launch: four lanes per agent, the agent's state, its obstacle slots
-// (four per lane), target index and PID state stay in registers, the course (at most 2048
-// way-points) and its run boxes are staged in LDS once per workgroup, the rows of each tick go
-// through the per-wavefront LDS table of the 4-lane filter kernel.  No HBM traffic inside the
-// loop except the optional trace.
-template <typename T, int RPL>
+// (RPL per lane), target index, PID and slip state stay in registers, the course and its run boxes
+// are staged in LDS (once per workgroup when it has at most 2048 way-points, else pass by pass on
+// every tick), the rows of each tick go through the per-wavefront LDS table of the 4-lane filter
+// kernel.  No HBM traffic inside the loop except the optional trace (and the course passes of a
+// long course).
+// EXT = false: the bicycle models whose rows lane_rows_ forms (DBM: u = (a, delta), vehicle step
+// update_com; KBM: u = (v, delta) with v the tracked speed, step update_by_vel);
+// EXT = true: the models of k_group_ext (DUM: u = (a, omega), omega_ref = v tan(delta_ref) / L, unicycle
+// step; SADBM: u = (a, delta) in and out, slip state per agent, every cone takes the agent's beta, step
+// update_com with the filter's delta).
+template <typename T, int RPL, bool EXT>
 __global__ __launch_bounds__(kBlock)
 __attribute__((amdgpu_waves_per_eu((sizeof(T) == 4 && RPL <= 4) ? SCCBF_ROLLOUT_WAVES : 1, SCCBF_ROLLOUT_WAVES)))
 void k_rollout(const RArgs<T> a)
@@ -430,9 +449,12 @@ void k_rollout(const RArgs<T> a)
     const int qslot = (int)(threadIdx.x / G) * kMpad;
     const v4* traj4 = reinterpret_cast<const v4*>(np.traj);
 
-    const bool course = np.N > 0;  // else the nominal input is zero
-    if (course) stage_course_<T, kBlock>(c, traj4, 0, np.N);
-    for (int i = threadIdx.x; i < np.N; i += kBlock) s_yaw[i] = traj4[i].z;
+    const bool course = np.N > 0;            // else the nominal input is zero
+    const bool one_pass = np.N <= kTrajChunk;  // the whole course fits the staging area
+    if (course && one_pass) {
+        stage_course_<T, kBlock>(c, traj4, 0, np.N);
+        for (int i = threadIdx.x; i < np.N; i += kBlock) s_yaw[i] = traj4[i].z;
+    }
 
     // this lane's obstacle slots (r G + g) and everything the agent carries from tick to tick
     LaneLoads<T, RPL> L;
@@ -446,42 +468,99 @@ void k_rollout(const RArgs<T> a)
     int tgt = course ? np.target_idx[ag] : 0;
     v2 ps = v2{T(0), T(0)};
     if (course && np.pid_state) ps = reinterpret_cast<v2*>(np.pid_state)[ag];
+    const bool sadbm = EXT && p.dynamics == SCCBF_DYN_SADBM;
+    v2 sl = v2{T(0), T(0)};  // SADBM: beta, beta_ref_last
+    if (sadbm) sl = reinterpret_cast<const v2*>(a.slip)[ag];
     T h_min = INFINITY;
     int n_act = 0, n_inf = 0;
     __syncthreads();
-    const int runs = (np.N + kSub - 1) / kSub;
 
     for (int tick = 0; tick < a.ticks; ++tick) {
         // nominal input
-        T acc = T(0), delta = T(0);
+        T acc = T(0), delta = T(0), v_track = T(0);
         if (course) {
-        T sth, cth;
-        sincos_(st.z, &sth, &cth);
-        const T fx = st.x + np.axle * cth, fy = st.y + np.axle * sth;
-        const int lt = min(max(tgt, 0), np.N - 1);
-        const T lx = c.x[(lt / kSub) * kSubStride + lt % kSub], ly = c.y[(lt / kSub) * kSubStride + lt % kSub];
-        T lim = len2_(fx - lx, fy - ly);
-        int ai = lt;
-        T best = INFINITY;
-        int bi = 0x7fffffff;
-        nearest_in_pass_(c, fx, fy, g, 0, runs, lim, ai, best, bi);
-        bi = group_nearest_(best, bi, np.N);
-        tgt = tgt >= bi ? tgt : bi;
-        const int ti = min(tgt, np.N - 1);
-        T v_des = np.target_speed;
-        if (np.flags & SCCBF_NOMINAL_WAYPOINT_SPEED) v_des = traj4[ti].w;
-        stanley_pid_(np, st.z, st.w, sth, cth, fx, fy, c.x[(bi / kSub) * kSubStride + bi % kSub],
-                     c.y[(bi / kSub) * kSubStride + bi % kSub], s_yaw[ti], v_des, np.pid_state != nullptr, ps,
-                     acc, delta);
+            T sth, cth;
+            sincos_(st.z, &sth, &cth);
+            const T fx = st.x + np.axle * cth, fy = st.y + np.axle * sth;
+            const int lt = min(max(tgt, 0), np.N - 1);
+            T lim, best = INFINITY;
+            int ai = lt, bi = 0x7fffffff;
+            if (one_pass) {
+                const T lx = c.x[(lt / kSub) * kSubStride + lt % kSub], ly = c.y[(lt / kSub) * kSubStride + lt % kSub];
+                lim = len2_(fx - lx, fy - ly);
+                nearest_in_pass_(c, fx, fy, g, 0, (np.N + kSub - 1) / kSub, lim, ai, best, bi);
+            } else {
+                const v2 wl = *reinterpret_cast<const v2*>(traj4 + lt);
+                lim = len2_(fx - wl.x, fy - wl.y);
+                for (int base = 0; base < np.N; base += kTrajChunk) {
+                    const int n = min(kTrajChunk, np.N - base);
+                    __syncthreads();
+                    stage_course_<T, kBlock>(c, traj4, base, n);
+                    __syncthreads();
+                    nearest_in_pass_(c, fx, fy, g, base, (n + kSub - 1) / kSub, lim, ai, best, bi);
+                }
+            }
+            bi = group_nearest_(best, bi, np.N);
+            tgt = tgt >= bi ? tgt : bi;
+            const int ti = min(tgt, np.N - 1);
+            T xn, yn, yaw_des, v_des = np.target_speed;
+            if (one_pass) {
+                xn = c.x[(bi / kSub) * kSubStride + bi % kSub];
+                yn = c.y[(bi / kSub) * kSubStride + bi % kSub];
+                yaw_des = s_yaw[ti];
+                if (np.flags & SCCBF_NOMINAL_WAYPOINT_SPEED) v_des = traj4[ti].w;
+            } else {
+                const v2 wn = *reinterpret_cast<const v2*>(traj4 + bi);
+                const v4 wt = traj4[ti];
+                xn = wn.x; yn = wn.y; yaw_des = wt.z; v_des = wt.w;
+            }
+            stanley_pid_(np, st.z, st.w, sth, cth, fx, fy, xn, yn, yaw_des, v_des, np.pid_state != nullptr, ps,
+                         acc, delta, &v_track);
         }
         // filter
-        L.sv = st;
-        L.urv = v2{acc, delta};
         Ego<T> e;
         T ur0, ur1;
         T at0[RPL], at1[RPL], bt[RPL];
         T hm = INFINITY;
-        int bad = lane_rows_<T, RPL, false>(p, ag, g, G, false, L, e, ur0, ur1, at0, at1, bt, &hm);
+        int bad;
+        T beta_ref = T(0);
+        if (!EXT) {
+            L.sv = st;
+            L.urv = p.dynamics == SCCBF_DYN_KBM ? v2{v_track, delta} : v2{acc, delta};
+            bad = lane_rows_<T, RPL, false>(p, ag, g, G, false, L, e, ur0, ur1, at0, at1, bt, &hm);
+        } else {
+            // as k_group_ext forms them
+            e.x = st.x; e.y = st.y; e.th = st.z; e.v = st.w;
+            ur0 = acc;
+            ur1 = sadbm ? delta : st.w * tan_(delta) * p.inv_L;
+            bad = !(finite_(ur0) && finite_(ur1) && finite_(e.x) && finite_(e.y) && finite_(e.th) && finite_(e.v) &&
+                    finite_(sl.x) && finite_(sl.y));
+            sincos_(e.th, &e.sth, &e.cth);
+            e.derive(p);
+            T cthb = e.cth, sthb = e.sth, sb = T(0);
+            e.un0 = ur0;
+            e.un1 = ur1;
+            if (sadbm) {
+                beta_ref = atan_(tan_(ur1) * p.k_in);
+                e.un1 = (beta_ref - sl.y) * a.inv_dt;
+                T cb;
+                sincos_(e.th + sl.x, &sthb, &cthb);
+                sincos_(sl.x, &sb, &cb);
+            }
+            T chk = T(0);
+#pragma unroll
+            for (int r = 0; r < RPL; ++r) {
+                const int m = g + r * G;
+                T o[8] = {L.oa[r].x, L.oa[r].y, L.oa[r].z, L.oa[r].w, L.ob[r].x, L.ob[r].y, L.ob[r].z, L.ob[r].w};
+                const int ty = m < p.M ? L.ty[r] : SCCBF_OBS_EMPTY;
+                T a0, a1, b, h;
+                ext_slot_row_(ty, o, e, p, sadbm, sadbm, sl.x, cthb, sthb, sb, a0, a1, b, h);
+                if (ty >= 0 && ty <= SCCBF_OBS_CONE_PREP) hm = min_(hm, h);
+                chk += a0 * T(0) + a1 * T(0) + b * T(0);
+                to_wspace_(a0, a1, b, e, p, at0[r], at1[r], bt[r]);
+            }
+            bad |= !(chk == T(0));
+        }
         bad = (int)group_or<G>((unsigned)bad);
 #pragma unroll
         for (int r = 0; r < RPL; ++r) {
@@ -493,14 +572,42 @@ void k_rollout(const RArgs<T> a)
         __builtin_amdgcn_wave_barrier();
         const Pivot<T> s = active_set_<T, G, RPL, true>(p.M, g, at0, at1, bt, s_rows, kPlane, qslot, bad);
         __builtin_amdgcn_wave_barrier();  // the table is rewritten next tick
-        const v2 u = result_u_(p, false, s.st, s.w0, s.w1, e, ur0, ur1);
         hm = min_(hm, __shfl_xor(hm, 1, 64));
         hm = min_(hm, __shfl_xor(hm, 2, 64));
         h_min = min_(h_min, hm);
         n_act += (s.st == SCCBF_STATUS_OPTIMAL) & ((s.w0 != T(0)) | (s.w1 != T(0)));
         n_inf += s.st == SCCBF_STATUS_INFEASIBLE;
-        // vehicle step, then the obstacles move
-        const T beta = vehicle_step_<T>(st, u.x, u.y, a.k_in, a.inv_lr, a.max_steer, a.dt);
+        // the filter's answer, the vehicle step, then the obstacles move
+        v2 u;
+        T beta = T(0);
+        if (!EXT) {
+            u = result_u_(p, false, s.st, s.w0, s.w1, e, ur0, ur1);
+            if (p.dynamics == SCCBF_DYN_KBM)
+                kin_step_<T>(st, SCCBF_STEP_KIN_VEL, u.x, u.y, p.inv_L, a.max_steer, a.dt);
+            else
+                beta = vehicle_step_<T>(st, u.x, u.y, a.k_in, a.inv_lr, a.max_steer, a.dt);
+        } else {
+            T u0 = e.un0, u1 = e.un1;
+            if (s.st == SCCBF_STATUS_OPTIMAL) {
+                const T y1 = s.w1 * p.inv_l11;
+                const T y0 = (s.w0 - p.l10 * y1) * p.inv_l00;
+                u0 += y0;
+                u1 += y1;
+            }
+            u = v2{u0, u1};
+            if (sadbm) {
+                if (s.st == SCCBF_STATUS_NONFINITE) {
+                    u = v2{ur0, ur1};  // inputs pass through, the slip state stays
+                } else {
+                    sl.x += u1 * a.dt;                       // reference cbf/cbf.py:421
+                    sl.y = beta_ref;
+                    u.y = atan_(tan_(sl.x) * p.k_out);       // cbf.py:430
+                }
+                beta = vehicle_step_<T>(st, u.x, u.y, a.k_in, a.inv_lr, a.max_steer, a.dt);
+            } else {
+                kin_step_<T>(st, SCCBF_STEP_UNICYCLE, u.x, u.y, p.inv_L, a.max_steer, a.dt);
+            }
+        }
         if (a.trace && live && g == 0)
             reinterpret_cast<v4*>(a.trace)[(long long)tick * p.A + ag] = v4{u.x, u.y, beta, (T)s.st};
         if (a.motion == SCCBF_MOTION_CONSTANT_VELOCITY) {
@@ -516,6 +623,7 @@ void k_rollout(const RArgs<T> a)
         reinterpret_cast<v4*>(a.state)[ag] = st;
         if (course) np.target_idx[ag] = tgt;
         if (course && np.pid_state) reinterpret_cast<v2*>(np.pid_state)[ag] = ps;
+        if (sadbm) reinterpret_cast<v2*>(a.slip)[ag] = sl;
         if (a.h_min) a.h_min[ag] = h_min;
         if (a.n_active) a.n_active[ag] = n_act;
         if (a.n_infeasible) a.n_infeasible[ag] = n_inf;

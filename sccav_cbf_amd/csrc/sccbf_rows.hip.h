@@ -364,6 +364,36 @@ __device__ inline T vehicle_step_(typename VT<T>::v4& s, T acc, T delta_in, T k_
     return beta;
 }
 
+// The kinematic steps of the drivers' State class, reference test_scripts/stanley_controller_ellipse.py:
+// update (86-100): u = (a, delta); update_by_vel (102-118): u = (v, delta), the speed is set, not
+// integrated; both normalise the yaw (cbf/utils.py:93-106).  SCCBF_STEP_UNICYCLE, u = (a, omega): the
+// Euler step of the model DUM_CBF_2DS filters (cbf/cbf.py:237-245); the reference ships no driver for it.
+template <typename T> __device__ inline T wrap_angle_(T a)
+{
+    constexpr T kPi = T(3.14159265358979323846), k2Pi = T(6.28318530717958647692);
+    a -= k2Pi * rint(a * (T(1) / k2Pi));
+    a = a > kPi ? a - k2Pi : a;
+    a = a < -kPi ? a + k2Pi : a;
+    return a;
+}
+template <typename T>
+__device__ inline void kin_step_(typename VT<T>::v4& s, int mode, T u0, T u1, T inv_L, T max_steer, T dt)
+{
+    T sth, cth;
+    sincos_(s.z, &sth, &cth);
+    const T v = s.w;
+    s.x += v * cth * dt;
+    s.y += v * sth * dt;
+    if (mode == SCCBF_STEP_UNICYCLE) {
+        s.z += u1 * dt;
+        s.w += u0 * dt;
+    } else {
+        const T delta = min_(max_(u1, -max_steer), max_steer);
+        s.z = wrap_angle_(s.z + v * inv_L * tan_(delta) * dt);
+        s.w = mode == SCCBF_STEP_KIN_VEL ? u0 : s.w + u0 * dt;
+    }
+}
+
 // The lane that holds the answer stores it and, where the caller asked for it (sccbf_solve_step_*),
 // moves the agent by one vehicle step with the filtered input.
 template <typename T>

@@ -95,6 +95,25 @@ def vehicle_step(state, u, lr=1.45, lf=1.45, max_steer=np.radians(30.0), dt=0.1,
     return state
 
 
+def vehicle_step_kin(state, u, mode, L=2.9, max_steer=np.radians(30.0), dt=0.1):
+    """In-place kinematic step of state (A,4) (sccbf_vehicle_step_kin_*): mode "acc" = State.update
+    with u = (a, delta), "vel" = State.update_by_vel with u = (v, delta) (reference
+    test_scripts/stanley_controller_ellipse.py:86-118), "unicycle" = u = (a, omega)."""
+    if not state.is_cuda:
+        raise _lib.SccbfError("vehicle_step_kin needs tensors on the GPU (no CPU fallback)")
+    ty, dev = state.dtype, state.device
+    A = state.shape[0]
+    _check("state", state, (A, 4), ty, dev)
+    _check("u", u, (A, 2), ty, dev)
+    code = {"acc": _lib.STEP_KIN_ACC, "vel": _lib.STEP_KIN_VEL, "unicycle": _lib.STEP_UNICYCLE}[mode]
+    lib = _lib.load()
+    fn = lib.sccbf_vehicle_step_kin_f32 if ty == torch.float32 else lib.sccbf_vehicle_step_kin_f64
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _lib.check(fn(A, _ptr(state), _ptr(u), code, float(L), float(max_steer), float(dt), C.c_void_p(stream)))
+    return state
+
+
 class ClosedLoop:
     """nominal -> filter -> vehicle step for a batch, every tensor resident on the GPU.
 
@@ -103,10 +122,11 @@ class ClosedLoop:
     runs: move them between ticks (or inside the captured region) with ordinary tensor ops.
 
     nominal=None, traj=None: no course, the nominal input is (0, 0) on every tick (the stationary
-    ego of test_scripts/radial_dynamic_obstacles.py:444).  With a steer-rate filter
-    (BatchedCBF(dynamics="sadbm")) tick() keeps the slip state in self.slip (beta, beta_ref_last) and
-    every cone follows the filter's beta, as reference cbf/cbf.py:424-427 leaves them; rollout() is
-    for the DBM filter."""
+    ego of test_scripts/radial_dynamic_obstacles.py:444).  The vehicle model follows the filter's:
+    "dbm" (a, delta) -> update_com; "kbm" (v, delta), v the tracked speed -> update_by_vel; "dum"
+    (a, omega = v tan(delta_ref) / L) -> unicycle step; "sadbm": the slip state lives in self.slip
+    (beta, beta_ref_last), every cone follows the filter's beta, as reference cbf/cbf.py:424-427 leaves
+    them, and the step is update_com with the filter's (a, delta).  tick() and rollout() agree."""
 
     def __init__(self, cbf: BatchedCBF, nominal: BatchedNominal, traj, state, obs, obs_type,
                  max_steer=np.radians(30.0), dt=0.1, use_pid_state=False):
@@ -183,7 +203,7 @@ class ClosedLoop:
         if flags & _lib.FLAG_OBS_SHARED:
             raise ValueError("rollout needs per-agent obstacle slots (planes or tiles)")
         if self.cbf.slip_io:
-            raise ValueError("rollout works in the caller's coordinates (a, delta): slip_io must be off")
+            raise ValueError("rollout works in the caller's coordinates (steering angles): slip_io must be off")
         if int(ticks) < 0:
             raise ValueError("ticks must not be negative")
         if not self.state.is_cuda:
@@ -215,7 +235,8 @@ class ClosedLoop:
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
             rc = fn(C.byref(params), C.byref(nominal_params), C.byref(rp), A, M, N,
-                    _ptr(self.state), _ptr(self.traj), _ptr(self.target_idx), _ptr(self.pid_state), _ptr(obs),
+                    _ptr(self.state), _ptr(self.traj), _ptr(self.target_idx), _ptr(self.pid_state),
+                    _ptr(self.slip), _ptr(obs),
                     _ptr(self.obs_type), _ptr(out["h_min"]), _ptr(out["n_active"]), _ptr(out["n_infeasible"]),
                     _ptr(out.get("trace")), C.c_void_p(stream))
         _lib.check(rc)
@@ -223,22 +244,33 @@ class ClosedLoop:
 
     def tick(self):
         dyn = self.cbf.params.dynamics
-        if dyn not in (_lib.DYN_DBM, _lib.DYN_SADBM) or (dyn == _lib.DYN_DBM and self.cbf.slip_io):
-            # the vehicle step below is update_com of the DBM drivers and takes (a, delta)
-            raise ValueError("ClosedLoop.tick steps the vehicle with (a, delta): use a DBM filter without "
-                             "slip_io or the steer-rate filter (KBM / DUM answers are (v, delta) / (a, omega))")
+        if self.cbf.slip_io:
+            raise ValueError("ClosedLoop works in the caller's coordinates (steering angles): slip_io must be off")
         self._check_inputs()
         if self.nominal is not None:
             self.nominal.control(self.state, self.traj, self.target_idx, self.pid_state, u_ref=self.u_ref)
-        if self.slip is not None:
+        if dyn == _lib.DYN_SADBM:
             self.cbf.solve(self.state, self.u_ref, self.obs, self.obs_type, u_out=self.u, status=self.status,
                            slip=self.slip, dt=self.dt, cone_beta_state=True)
-        elif self.cbf.params.dynamics == _lib.DYN_DBM and not self.cbf.slip_io:
+        elif dyn == _lib.DYN_DBM:
             # filter and vehicle step in one launch
             self.cbf.solve(self.state, self.u_ref, self.obs, self.obs_type, u_out=self.u, status=self.status,
                            step_dt=self.dt, max_steer=self.max_steer, beta_out=self.beta)
             return
-        else:
+        elif dyn == _lib.DYN_KBM:
+            # u_ref = (tracked speed, delta_ref): the drivers hand KBM_VC_CBF2D the target speed itself
+            # (stanley_controller_ellipse.py:633, 711), then update_by_vel (102-118)
+            if self.nominal is not None:
+                wps = self.nominal.params.flags & _lib.NOMINAL_WAYPOINT_SPEED
+                self.u_ref[:, 0] = (self.traj[self.target_idx.long().clamp(max=self.traj.shape[0] - 1), 3]
+                                    if wps else self.nominal.params.target_speed)
             self.cbf.solve(self.state, self.u_ref, self.obs, self.obs_type, u_out=self.u, status=self.status)
+            vehicle_step_kin(self.state, self.u, "vel", L=self.cbf.params.L, max_steer=self.max_steer, dt=self.dt)
+            return
+        else:  # DUM: the yaw rate of the nominal steering, then the unicycle step
+            self.u_ref[:, 1] = self.state[:, 3] * torch.tan(self.u_ref[:, 1]) / self.cbf.params.L
+            self.cbf.solve(self.state, self.u_ref, self.obs, self.obs_type, u_out=self.u, status=self.status)
+            vehicle_step_kin(self.state, self.u, "unicycle", dt=self.dt)
+            return
         vehicle_step(self.state, self.u, lr=self.cbf.params.lr, lf=self.cbf.params.lf,
                      max_steer=self.max_steer, dt=self.dt, beta_out=self.beta)

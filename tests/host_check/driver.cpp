@@ -39,9 +39,19 @@ int main()
     expect(sccbf_solve_step_f64(&p, -1.0, 0.1, 0, 4, 0, 0, 0, 0, 0, 0, 0, 0), -1, "solve_step max_steer");
     expect(sccbf_solve_step_f32(0, 0.5, 0.1, 0, 4, 0, 0, 0, 0, 0, 0, 0, 0), -1, "solve_step null params");
     rp.ticks = 3;
-    expect(sccbf_rollout_f32(&p, &np, &rp, 0, 4, 10, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0), 0, "rollout empty");
-    expect(sccbf_rollout_f64(&p, &np, &rp, 4, 65, 10, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0), -2, "rollout slots");
-    for (int m = -1; m <= 4; ++m) { rp.motion = m; sccbf_rollout_f32(&p, &np, &rp, 4, 4, 10, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0); }
+    expect(sccbf_rollout_f32(&p, &np, &rp, 0, 4, 10, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0), 0, "rollout empty");
+    expect(sccbf_rollout_f64(&p, &np, &rp, 4, 65, 10, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0), -2, "rollout slots");
+    for (int m = -1; m <= 4; ++m) { rp.motion = m; sccbf_rollout_f32(&p, &np, &rp, 4, 4, 10, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0); }
+    for (int d = 0; d <= 3; ++d) { p.dynamics = d; sccbf_rollout_f64(&p, &np, &rp, 4, 4, 3000, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0); }
+    p.dynamics = 0; rp.motion = 0;
+    p.flags = 4u; expect(sccbf_rollout_f32(&p, &np, &rp, 4, 4, 10, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0), -1, "rollout slip io"); p.flags = 0;
+    expect(sccbf_vehicle_step_kin_f32(0, 0, 0, 1, 2.9, 0.5, 0.1, 0), 0, "kin step empty");
+    expect(sccbf_vehicle_step_kin_f64(4, 0, 0, 3, 2.9, 0.5, 0.1, 0), -1, "kin step mode");
+    expect(sccbf_vehicle_step_kin_f64(4, 0, 0, 0, 0.0, 0.5, 0.1, 0), -1, "kin step L");
+    expect(sccbf_vehicle_step_kin_f32(4, 0, 0, 2, 0.0, 0.5, 0.1, 0), -1, "kin step null");
+    expect(sccbf_prepare_obs_f32(0, 4, 0, 0, 0, 0), 0, "prepare empty");
+    expect(sccbf_prepare_obs_f64(4, 4, 0, 0, 0, 0), -1, "prepare null");
+    expect(sccbf_prepare_obs_f32(4, 4, 0, 0, 1u | 8u, 0), -1, "prepare flags");
     expect(sccbf_ingest_bbox_f32(0, 4, 0, 0, 0.5, 0, 0, 0), 0, "ingest empty");
     expect(sccbf_ingest_bbox_f64(4, 4, 0, 0, 0.5, 0, 0, 0), -1, "ingest null");
     expect(sccbf_lane_fit_f32(0, 8, 3, 0, 0, 0, 1.5, 0, 2, 0, 0, 0), 0, "fit empty");

@@ -98,12 +98,12 @@ def test_rollout_argument_validation(lib):
     p, q = _lib.Params(), _lib.NominalParams()
     lib.sccbf_default_params(C.byref(p))
     lib.sccbf_default_nominal_params(C.byref(q))
-    nul = (C.c_void_p(0),) * 11
+    nul = (C.c_void_p(0),) * 12
     r.ticks = 5
     call = lambda A, M, N: lib.sccbf_rollout_f32(C.byref(p), C.byref(q), C.byref(r), A, M, N, *nul)
     assert call(0, 4, 100) == 0                      # empty batch
     assert call(8, 4, 100) == -1                     # null data
-    assert call(8, 4, 2049) == -2                    # course longer than one LDS pass
+    assert call(8, 4, 2049) == -1                    # a long course is fine (staged pass by pass): null data
     assert call(8, 65, 100) == -2                    # more slots than four lanes hold
     assert call(8, 0, 100) == -1 and call(8, 4, -1) == -1
     assert call(0, 4, 0) == 0                        # no course: the nominal input is zero
@@ -112,9 +112,14 @@ def test_rollout_argument_validation(lib):
     r.motion, r.seek_gain = 2, -1.0
     assert call(8, 4, 100) == -1                     # seeker law needs gains >= 0
     r.motion, r.seek_gain = 0, 0.2
-    p.dynamics = 1
-    assert call(8, 4, 100) == -1                     # the vehicle step is the DBM one
-    p.dynamics = 0
+    for dyn in (1, 2, 3):
+        p.dynamics = dyn
+        assert call(0, 4, 100) == 0                  # every model has its loop
+    p.dynamics, p.L = 1, 0.0
+    assert call(0, 4, 100) == -1                     # the kinematic step needs the wheel base
+    p.dynamics, p.L, p.flags = 0, 2.9, 4
+    assert call(0, 4, 100) == -1                     # steering angles, not slip angles
+    p.flags = 0
     assert lib.sccbf_rollout_f64(None, C.byref(q), C.byref(r), 8, 4, 100, *nul) == -1
 
 

@@ -206,12 +206,20 @@ def test_closed_loop_rejects_mismatched_tensors_before_any_launch():
         ClosedLoop(flt, None, **ok)                    # a course without a controller
 
 
-def test_closed_loop_tick_refuses_models_the_vehicle_step_does_not_fit():
+def test_closed_loop_refuses_slip_coordinates():
+    """tick() and rollout() step the vehicle with steering angles; a filter set to slip-angle I/O would
+    hand them something else."""
+    from sccav_cbf_amd import _lib
     from sccav_cbf_amd.batched import BatchedCBF
     from sccav_cbf_amd.nominal import BatchedNominal, ClosedLoop
-    for kw in (dict(dynamics="kbm"), dict(dynamics="dum"), dict(dynamics="dbm", slip_io=True)):
-        loop = ClosedLoop(BatchedCBF(**kw), BatchedNominal(), **_closed_loop_parts())
-        with pytest.raises(ValueError, match="a, delta"):
+    loop = ClosedLoop(BatchedCBF(dynamics="dbm", slip_io=True), BatchedNominal(), **_closed_loop_parts())
+    with pytest.raises(ValueError, match="slip_io"):
+        loop.tick()
+    with pytest.raises(ValueError, match="slip_io"):
+        loop.rollout(2)
+    for dyn in ("kbm", "dum", "sadbm"):             # every model has its step: only the GPU is missing here
+        loop = ClosedLoop(BatchedCBF(dynamics=dyn), BatchedNominal(), **_closed_loop_parts())
+        with pytest.raises(_lib.SccbfError):
             loop.tick()
 
 

@@ -514,3 +514,106 @@ def test_nearest_waypoint_of_agents_far_off_the_course(dtype):
         # Python 3.10 has no math.fma: the unfused sum may differ in the last bit, which can reorder exact-looking ties
         assert ok.mean() >= 0.98 and (ok | (np.abs(d[np.arange(A), np.minimum(got, N - 1)] - d.min(axis=1))
                                             <= 4e-16 * d.min(axis=1))).all()
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("mode", ["acc", "vel", "unicycle"])
+def test_kinematic_steps_match_the_restated_driver_steps(oracle, dtype, mode):
+    from sccav_cbf_amd.nominal import vehicle_step_kin
+    rng = np.random.default_rng(5)
+    A = 3000
+    state = np.stack([rng.uniform(-50, 50, A), rng.uniform(-50, 50, A), rng.uniform(-7, 7, A), rng.uniform(0, 15, A)], 1)
+    u = np.stack([rng.uniform(-3, 12, A), rng.uniform(-0.9, 0.9, A)], 1)
+    s = torch.from_numpy(state).to(DEV).to(dtype)
+    want = s.double().cpu().numpy().copy()
+    ud = torch.from_numpy(u).to(DEV).to(dtype)
+    vehicle_step_kin(s, ud, mode, L=2.9, max_steer=np.radians(30.0), dt=0.1)
+    oracle.vehicle_step_kin_batch(want, ud.double().cpu().numpy(), mode, 2.9, np.radians(30.0), 0.1)
+    torch.cuda.synchronize()
+    got = s.double().cpu().numpy()
+    d = np.abs(got - want)
+    d[:, 2] = np.minimum(d[:, 2], np.abs(d[:, 2] - 2 * np.pi))     # -pi and pi are the same heading
+    assert d.max() <= (1e-12 if dtype == torch.float64 else 2e-5)
+
+
+def _model_loop(dyn, A, M, seed, dtype, N=None, tiled=False):
+    from sccav_cbf_amd import scenarios
+    from sccav_cbf_amd.batched import BatchedCBF, planes_to_tiled
+    from sccav_cbf_amd.nominal import BatchedNominal, ClosedLoop
+    traj = _course()
+    if N is not None:          # a longer course: the same curve sampled more finely
+        t = np.linspace(0, traj.shape[0] - 1, N)
+        traj = np.stack([np.interp(t, np.arange(traj.shape[0]), traj[:, k]) for k in range(4)], axis=1)
+    w = scenarios.monte_carlo(A, (M + 1) // 2, M // 2, seed, nominal="uniform")
+    rng = np.random.default_rng(seed)
+    at = rng.integers(0, traj.shape[0] - traj.shape[0] // 6, A)
+    xy = np.stack([traj[at, 0] + rng.normal(0, 2, A), traj[at, 1] + rng.normal(0, 2, A)], axis=1)
+    w["obs"][:, 0, :, 0:2] += (xy - w["state"][:, 0:2])[None, :, :]
+    w["state"][:, 0:2] = xy
+    w["state"][:, 2] = traj[at, 2] + rng.normal(0, 0.2, A)
+    w["state"][:, 3] = rng.uniform(3, 12, A)
+
+    def make():
+        obs = torch.from_numpy(w["obs"]).to(DEV).to(dtype)
+        return ClosedLoop(BatchedCBF(alpha=1.0, R=np.diag([0.5, 0.5]), dynamics=dyn),
+                          BatchedNominal(axle=2.9, k=0.5, ks=0.01, kp=1.0, ki=0.2, kd=0.02, dt=0.1),
+                          torch.from_numpy(traj).to(DEV).to(dtype), torch.from_numpy(w["state"]).to(DEV).to(dtype),
+                          planes_to_tiled(obs) if tiled else obs, torch.from_numpy(w["obs_type"]).to(DEV),
+                          use_pid_state=True)
+    return make
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("dyn,M,tiled", [("kbm", 12, False), ("dum", 16, True), ("sadbm", 9, False), ("sadbm", 40, True)])
+def test_rollout_of_every_model_equals_its_ticks(dtype, dyn, M, tiled):
+    """sccbf_rollout_* for the kinematic, unicycle-input and steer-rate models against ClosedLoop.tick
+    (nominal -> the model's solve entry -> the model's vehicle step) launched tick by tick."""
+    A, T = 300, 20
+    make = _model_loop(dyn, A, M, 90 + M, dtype, tiled=tiled)
+    la = make()
+    tr = []
+    for _ in range(T):
+        la.tick()
+        tr.append(torch.cat([la.u, la.status.to(dtype)[:, None]], dim=1).clone())
+    tr = torch.stack(tr)
+    lb = make()
+    out = lb.rollout(T, trace=True)
+    torch.cuda.synchronize()
+    tol = 1e-6 if dtype == torch.float64 else 5e-3
+    same = (out["trace"][:, :, 3] == tr[:, :, 2]).all(dim=0)
+    assert same.float().mean().item() >= (0.99 if dtype == torch.float64 else 0.95)
+    scale = 1 + tr[:, :, :2].abs().amax(dim=(0, 2))
+    same &= scale < 1e3                               # agents driven off by an unbounded QP amplify every last bit
+    assert same.float().mean().item() >= 0.8
+    d = ((out["trace"][:, :, :2] - tr[:, :, :2]).abs().amax(dim=(0, 2)) / scale)[same].max().item()
+    assert d <= tol, d
+    ds = (lb.state - la.state).abs()
+    ds[:, 2] = torch.minimum(ds[:, 2], (ds[:, 2] - 2 * np.pi).abs())
+    assert (ds.amax(dim=1) / scale)[same].max().item() <= tol * 50
+    assert (lb.target_idx[same] - la.target_idx[same]).abs().max().item() <= (0 if dtype == torch.float64 else 1)
+    if dyn == "sadbm":
+        assert ((lb.slip - la.slip).abs().amax(dim=1) / scale)[same].max().item() <= tol * 50
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
+def test_rollout_on_a_course_longer_than_one_staging_pass(dtype):
+    """5000 way-points: the rollout stages the course pass by pass on every tick; against the ticks."""
+    A, T = 200, 12
+    make = _model_loop("dbm", A, 8, 7, dtype, N=5000)
+    la = make()
+    tr = []
+    for _ in range(T):
+        la.tick()
+        tr.append(torch.cat([la.u, la.status.to(dtype)[:, None]], dim=1).clone())
+    tr = torch.stack(tr)
+    lb = make()
+    out = lb.rollout(T, trace=True)
+    torch.cuda.synchronize()
+    tol = 1e-6 if dtype == torch.float64 else 5e-3
+    same = (out["trace"][:, :, 3] == tr[:, :, 2]).all(dim=0)
+    assert same.float().mean().item() >= (0.99 if dtype == torch.float64 else 0.95)
+    scale = 1 + tr[:, :, :2].abs().amax(dim=(0, 2))
+    same &= scale < 1e3
+    assert same.float().mean().item() >= 0.8
+    assert ((out["trace"][:, :, :2] - tr[:, :, :2]).abs().amax(dim=(0, 2)) / scale)[same].max().item() <= tol
+    assert (lb.target_idx[same] - la.target_idx[same]).abs().max().item() <= (0 if dtype == torch.float64 else 1)
