@@ -73,7 +73,7 @@ extern "C" {
                            (a drives v, omega drives yaw), drift [v cos, v sin, 0, 0]; as written the
                            drift is declared 5x1 with four entries (243-245) and the class does not run:
                            here with the 4x1 drift.  No steering transform (247-298 apply none).
-                           M <= 256 (SCCBF_ERR_ROWS beyond) */
+                           lanes_per_qp 0, 4 (M <= 64), 16 (M <= 256) or 64 */
 #define SCCBF_DYN_SADBM 3 /* SADBM_CBF_2DS, reference cbf/cbf.py:301-437: slip angle beta is a fifth
                              state, u = [a, d(beta)/dt].  Only through sccbf_solve_sa_* */
 
@@ -106,7 +106,7 @@ extern "C" {
 #define SCCBF_OK 0
 #define SCCBF_ERR_ARG (-1)         /* NULL pointer / negative size / A >= 2^31 / bad enum or flags */
 #define SCCBF_ERR_ROWS (-2)        /* M above SCCBF_MAX_ROWS, or above the limit stated at the entry point
-                                      (256 rows for the DUM / SADBM models, 64 slots for the rollout) */
+                                      (64 slots for the rollout) */
 #define SCCBF_ERR_WEIGHT (-3)      /* R not symmetric positive definite */
 #define SCCBF_ERR_LAUNCH (-4)      /* hipLaunch failed */
 #define SCCBF_ERR_VARIANT (-5)     /* lanes_per_qp cannot hold M rows */
@@ -179,8 +179,8 @@ int sccbf_solve_f64(const sccbf_params* p, int64_t A, int32_t M,
  * SCCBF_STATUS_INFEASIBLE: the nominal input is applied (beta += beta_dot_ref dt, u_out from it).
  * SCCBF_STATUS_NONFINITE: u_out = u_ref and the slip state is left as it was.
  * Cone slots read their own beta o[5] unless SCCBF_FLAG_CONE_BETA_STATE is set.
- * p->dynamics is ignored; SCCBF_FLAG_SLIP_IO is not allowed; 1 <= M <= 256 (an empty list raises
- * in the reference, 375-378); rows_out as in sccbf_solve_*.
+ * p->dynamics is ignored; SCCBF_FLAG_SLIP_IO is not allowed; M >= 1 (an empty list raises
+ * in the reference, 375-378); rows_out as in sccbf_solve_*; lanes_per_qp 0, 4 (M <= 64), 16 (M <= 256) or 64.
  */
 int sccbf_solve_sa_f32(const sccbf_params* p, double dt, int64_t A, int32_t M,
                        const float* state, float* slip, const float* u_ref,

@@ -174,14 +174,28 @@ int launch_ext_rpl(const KArgs<T>& k, const XArgs<T>& x, hipStream_t s)
 }
 
 template <typename T>
+int launch_wave_ext(const KArgs<T>& k, const XArgs<T>& x, hipStream_t s)
+{
+    const size_t per_wave = (size_t)3 * k.M * sizeof(T);
+    if (per_wave * 4 <= 48 * 1024) {
+        const long long blocks = (k.A + 3) / 4;
+        if (blocks > 0x7fffffffLL) return SCCBF_ERR_ARG;
+        hipLaunchKernelGGL((k_wave_ext<T, 4>), dim3((unsigned)blocks), dim3(256), per_wave * 4, s, k, x);
+    } else {
+        hipLaunchKernelGGL((k_wave_ext<T, 1>), dim3((unsigned)k.A), dim3(64), per_wave, s, k, x);
+    }
+    return hipGetLastError() == hipSuccess ? SCCBF_OK : SCCBF_ERR_LAUNCH;
+}
+
+template <typename T>
 int dispatch_ext(const sccbf_params* sp, const KArgs<T>& k, const XArgs<T>& x, void* stream)
 {
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (k.M > 256) return SCCBF_ERR_ROWS;
     int lanes = sp->lanes_per_qp;
-    if (lanes == 0) lanes = (k.A >= (1 << 13) && k.M <= 64) ? 4 : 16;
+    if (lanes == 0) lanes = k.M > 256 ? 64 : ((k.A >= (1 << 13) && k.M <= 64) ? 4 : 16);
     if (lanes == 4 && k.M <= 64) return launch_ext_rpl<T, 4>(k, x, s);
-    if (lanes == 16) return launch_ext_rpl<T, 16>(k, x, s);
+    if (lanes == 16 && k.M <= 256) return launch_ext_rpl<T, 16>(k, x, s);
+    if (lanes == 64) return launch_wave_ext<T>(k, x, s);
     return SCCBF_ERR_VARIANT;
 }
 

@@ -56,38 +56,88 @@ __device__ inline void ext_slot_row_(int type, T (&o)[8], const Ego<T>& e, const
     }
 }
 
+// Everything of one QP of these models that does not depend on a slot: the agent's state, its
+// nominal input in QP coordinates and, for the steer-rate model, the slip state and its sines / cosines.
+template <typename T> struct ExtEgo {
+    Ego<T> e;
+    T ur0, ur1;
+    typename VT<T>::v2 sl;  // SADBM: beta, beta_ref_last
+    T beta_ref, cthb, sthb, sb;
+    bool sadbm, cone_beta_state;
+    int bad;
+};
+
+template <typename T>
+__device__ inline void ext_prologue_(const KArgs<T>& p, const XArgs<T>& x, long long qp,
+                                     const typename VT<T>::v4& sv, const typename VT<T>::v2& urv, ExtEgo<T>& q)
+{
+    using v2 = typename VT<T>::v2;
+    Ego<T>& e = q.e;
+    q.sadbm = p.dynamics == SCCBF_DYN_SADBM;
+    q.sl = v2{T(0), T(0)};
+    if (q.sadbm) q.sl = reinterpret_cast<const v2*>(x.slip)[qp];
+    e.x = sv.x; e.y = sv.y; e.th = sv.z; e.v = sv.w;
+    q.ur0 = urv.x;
+    q.ur1 = urv.y;
+    q.bad = !(finite_(q.ur0) && finite_(q.ur1) && finite_(e.x) && finite_(e.y) && finite_(e.th) && finite_(e.v) &&
+              finite_(q.sl.x) && finite_(q.sl.y));
+    sincos_(e.th, &e.sth, &e.cth);
+    e.derive(p);
+    q.beta_ref = T(0);
+    q.cthb = e.cth;
+    q.sthb = e.sth;
+    q.sb = T(0);
+    e.un0 = q.ur0;
+    e.un1 = q.ur1;
+    if (q.sadbm) {
+        q.beta_ref = atan_(tan_(q.ur1) * p.k_in);       // reference cbf/cbf.py:359
+        e.un1 = (q.beta_ref - q.sl.y) * x.inv_dt;       // cbf.py:367-372
+        T cb;
+        sincos_(e.th + q.sl.x, &q.sthb, &q.cthb);
+        sincos_(q.sl.x, &q.sb, &cb);
+    }
+    q.cone_beta_state = q.sadbm && (p.flags & SCCBF_FLAG_CONE_BETA_STATE) != 0;
+}
+
+// u = u_nom + Lc^-T w, or the nominal input when the QP has no answer; SADBM integrates its slip angle
+template <typename T>
+__device__ inline void ext_epilogue_(const KArgs<T>& p, const XArgs<T>& x, long long qp, const ExtEgo<T>& q,
+                                     int st, T w0, T w1)
+{
+    using v2 = typename VT<T>::v2;
+    T u0 = q.e.un0, u1 = q.e.un1;
+    if (st == SCCBF_STATUS_OPTIMAL) {
+        const T y1 = w1 * p.inv_l11;
+        const T y0 = (w0 - p.l10 * y1) * p.inv_l00;
+        u0 += y0;
+        u1 += y1;
+    }
+    v2 out = v2{u0, u1};
+    if (q.sadbm) {
+        if (st == SCCBF_STATUS_NONFINITE) {
+            out = v2{q.ur0, q.ur1};  // nothing to integrate: inputs pass through, the slip state stays
+        } else {
+            const T beta = q.sl.x + u1 * x.dt;          // reference cbf/cbf.py:421
+            out.y = atan_(tan_(beta) * p.k_out);        // cbf.py:430
+            reinterpret_cast<v2*>(x.slip)[qp] = v2{beta, q.beta_ref};
+        }
+    }
+    reinterpret_cast<v2*>(p.u_out)[qp] = out;
+    p.status[qp] = st;
+}
+
 template <typename T, int G, int RPL>
 __global__ __launch_bounds__(kBlock) void k_group_ext(const KArgs<T> p, const XArgs<T> x)
 {
     using v4 = typename VT<T>::v4;
-    using v2 = typename VT<T>::v2;
     const int g = (int)(threadIdx.x % G);
     const long long qp = (long long)blockIdx.x * (kBlock / G) + threadIdx.x / G;
     if (qp >= p.A) return;  // groups are lane-aligned: a whole group leaves together
-    const bool sadbm = p.dynamics == SCCBF_DYN_SADBM;
-    v2 sl = v2{T(0), T(0)};
-    if (sadbm) sl = reinterpret_cast<const v2*>(x.slip)[qp];
     LaneLoads<T, RPL> L;
     group_load_<T, RPL, false, false>(p, qp, g, G, L);
-
-    Ego<T> e;
-    e.x = L.sv.x; e.y = L.sv.y; e.th = L.sv.z; e.v = L.sv.w;
-    const T ur0 = L.urv.x, ur1 = L.urv.y;
-    int bad = !(finite_(ur0) && finite_(ur1) && finite_(e.x) && finite_(e.y) && finite_(e.th) && finite_(e.v) &&
-                finite_(sl.x) && finite_(sl.y));
-    sincos_(e.th, &e.sth, &e.cth);
-    e.derive(p);
-    T beta_ref = T(0), cthb = e.cth, sthb = e.sth, sb = T(0);
-    e.un0 = ur0;
-    e.un1 = ur1;
-    if (sadbm) {
-        beta_ref = atan_(tan_(ur1) * p.k_in);       // reference cbf/cbf.py:359
-        e.un1 = (beta_ref - sl.y) * x.inv_dt;       // cbf.py:367-372
-        T cb;
-        sincos_(e.th + sl.x, &sthb, &cthb);
-        sincos_(sl.x, &sb, &cb);
-    }
-    const bool cone_beta_state = sadbm && (p.flags & SCCBF_FLAG_CONE_BETA_STATE) != 0;
+    ExtEgo<T> q;
+    ext_prologue_(p, x, qp, L.sv, L.urv, q);
+    int bad = q.bad;
 
     T at0[RPL], at1[RPL], bt[RPL];
     T chk = T(0);
@@ -97,10 +147,10 @@ __global__ __launch_bounds__(kBlock) void k_group_ext(const KArgs<T> p, const XA
         T o[8] = {L.oa[r].x, L.oa[r].y, L.oa[r].z, L.oa[r].w, L.ob[r].x, L.ob[r].y, L.ob[r].z, L.ob[r].w};
         const int ty = m < p.M ? L.ty[r] : SCCBF_OBS_EMPTY;
         T a0, a1, b, h;
-        ext_slot_row_(ty, o, e, p, sadbm, cone_beta_state, sl.x, cthb, sthb, sb, a0, a1, b, h);
+        ext_slot_row_(ty, o, q.e, p, q.sadbm, q.cone_beta_state, q.sl.x, q.cthb, q.sthb, q.sb, a0, a1, b, h);
         if (p.rows_out && m < p.M) reinterpret_cast<v4*>(p.rows_out)[(long long)m * p.A + qp] = v4{a0, a1, b, h};
         chk += a0 * T(0) + a1 * T(0) + b * T(0);
-        to_wspace_(a0, a1, b, e, p, at0[r], at1[r], bt[r]);
+        to_wspace_(a0, a1, b, q.e, p, at0[r], at1[r], bt[r]);
     }
     bad |= !(chk == T(0));
     bad = (int)group_or<G>((unsigned)bad);
@@ -122,27 +172,53 @@ __global__ __launch_bounds__(kBlock) void k_group_ext(const KArgs<T> p, const XA
     }
     const Pivot<T> s = active_set_<T, G, RPL, kLdsPick>(p.M, g, at0, at1, bt, s_rows, kPlane, qslot, bad);
     if (g != 0) return;
+    ext_epilogue_(p, x, qp, q, s.st, s.w0, s.w1);
+}
 
-    // u = u_nom + Lc^-T w, or the nominal input when the QP has no answer
-    T u0 = e.un0, u1 = e.un1;
-    if (s.st == SCCBF_STATUS_OPTIMAL) {
-        const T y1 = s.w1 * p.inv_l11;
-        const T y0 = (s.w0 - p.l10 * y1) * p.inv_l00;
-        u0 += y0;
-        u1 += y1;
+// One wavefront per QP, rows staged in LDS: any M up to SCCBF_MAX_ROWS (k_wave for these models).
+template <typename T, int WPB>
+__global__ __launch_bounds__(WPB * 64) void k_wave_ext(const KArgs<T> p, const XArgs<T> x)
+{
+    using v4 = typename VT<T>::v4;
+    using v2 = typename VT<T>::v2;
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    const int M = p.M;
+    T* s_at0 = reinterpret_cast<T*>(smem_raw) + (size_t)wv * 3 * M;
+    T* s_at1 = s_at0 + M;
+    T* s_bt = s_at1 + M;
+
+    long long qp = (long long)blockIdx.x * WPB + wv;
+    const bool live = qp < p.A;
+    if (!live) qp = p.A - 1;  // keep the wave for the block barrier; its stores are masked
+
+    const bool type_pa = (p.flags & SCCBF_FLAG_TYPE_PER_AGENT) != 0;
+    const v4* obs4 = reinterpret_cast<const v4*>(p.obs);
+    const ObsAddr oad = obs_addr_(p, qp);
+    ExtEgo<T> q;
+    ext_prologue_(p, x, qp, reinterpret_cast<const v4*>(p.state)[qp], reinterpret_cast<const v2*>(p.u_ref)[qp], q);
+    int bad = q.bad;
+    for (int m = lane; m < M; m += 64) {
+        const long long i0 = oad.at(m);
+        const v4 oa = obs4[i0];
+        const v4 ob = obs4[i0 + oad.half];
+        const int ty = type_pa ? p.obs_type[(long long)m * p.A + qp] : p.obs_type[m];
+        T o[8] = {oa.x, oa.y, oa.z, oa.w, ob.x, ob.y, ob.z, ob.w};
+        T a0, a1, b, h;
+        ext_slot_row_(ty, o, q.e, p, q.sadbm, q.cone_beta_state, q.sl.x, q.cthb, q.sthb, q.sb, a0, a1, b, h);
+        if (p.rows_out && live) reinterpret_cast<v4*>(p.rows_out)[(long long)m * p.A + qp] = v4{a0, a1, b, h};
+        bad |= !(finite_(a0) && finite_(a1) && finite_(b));
+        T t0, t1, tb;
+        to_wspace_(a0, a1, b, q.e, p, t0, t1, tb);
+        s_at0[m] = t0;
+        s_at1[m] = t1;
+        s_bt[m] = tb;
     }
-    v2 out = v2{u0, u1};
-    if (sadbm) {
-        if (s.st == SCCBF_STATUS_NONFINITE) {
-            out = v2{ur0, ur1};  // nothing to integrate: inputs pass through, the slip state stays
-        } else {
-            const T beta = sl.x + u1 * x.dt;            // reference cbf/cbf.py:421
-            out.y = atan_(tan_(beta) * p.k_out);        // cbf.py:430
-            reinterpret_cast<v2*>(x.slip)[qp] = v2{beta, beta_ref};
-        }
-    }
-    reinterpret_cast<v2*>(p.u_out)[qp] = out;
-    p.status[qp] = s.st;
+    bad = __any(bad);
+    __syncthreads();
+    const Pivot<T> s = wave_active_set_<T>(M, lane, s_at0, s_at1, s_bt, bad);
+    if (lane == 0 && live) ext_epilogue_(p, x, qp, q, s.st, s.w0, s.w1);
 }
 
 }  // namespace

@@ -213,6 +213,36 @@ __global__ __launch_bounds__(kBlock) void k_group(long long A, const T* obs, con
 }
 
 // ------------------------------------------ one wavefront per QP, rows staged in LDS
+// The active-set iteration of one wavefront on the M rows it has staged in LDS: every lane scans
+// rows lane, lane + 64, ..., the most violated row comes from a wave-wide max, the pivot reads it
+// by index (broadcast reads).
+template <typename T>
+__device__ inline Pivot<T> wave_active_set_(int M, int lane, const T* s_at0, const T* s_at1, const T* s_bt, int bad)
+{
+    Pivot<T> s;
+    s.reset(bad ? SCCBF_STATUS_NONFINITE : SCCBF_STATUS_OPTIMAL);
+    const int cap = kCapPerRow * M + kCapBase;
+    for (int it = 0;; ++it) {  // wave-uniform loop
+        const T thr = Lim<T>::viol_tol * (abs_(s.w0) + abs_(s.w1)) + Lim<T>::tiny_n2;
+        unsigned kbest = 0u;
+        for (int m = lane; m < M; m += 64) {
+            const T viol = s_bt[m] - (s_at0[m] * s.w0 + s_at1[m] * s.w1);
+            const unsigned key = viol > thr ? ((viol_bits_pos(viol) & ~0x3FFu) | (unsigned)(1023 - m)) : 0u;
+            kbest = key > kbest ? key : kbest;
+        }
+        const unsigned kmax = group_umax<64>(kbest);
+        const bool go = (s.st == SCCBF_STATUS_OPTIMAL) & (kmax != 0u);
+        if (!go) break;
+        if (it >= cap) {
+            s.st = SCCBF_STATUS_INFEASIBLE;
+            break;
+        }
+        const int sel = 1023 - (int)(kmax & 0x3FFu);
+        pivot_onto_(s, s_at0[sel], s_at1[sel], s_bt[sel], true);  // broadcast reads
+    }
+    return s;
+}
+
 template <typename T, int WPB, bool QP_ONLY>
 __global__ __launch_bounds__(WPB * 64) void k_wave(const KArgs<T> p)
 {
@@ -262,31 +292,8 @@ __global__ __launch_bounds__(WPB * 64) void k_wave(const KArgs<T> p)
     }
     bad = __any(bad);
     __syncthreads();
-
-    Pivot<T> s;
-    s.reset(bad ? SCCBF_STATUS_NONFINITE : SCCBF_STATUS_OPTIMAL);
-    const int cap = kCapPerRow * M + kCapBase;
-    for (int it = 0;; ++it) {  // wave-uniform loop
-        const T thr = Lim<T>::viol_tol * (abs_(s.w0) + abs_(s.w1)) + Lim<T>::tiny_n2;
-        unsigned kbest = 0u;
-        for (int m = lane; m < M; m += 64) {
-            const T viol = s_bt[m] - (s_at0[m] * s.w0 + s_at1[m] * s.w1);
-            const unsigned key = viol > thr ? ((viol_bits_pos(viol) & ~0x3FFu) | (unsigned)(1023 - m)) : 0u;
-            kbest = key > kbest ? key : kbest;
-        }
-        const unsigned kmax = group_umax<64>(kbest);
-        const bool go = (s.st == SCCBF_STATUS_OPTIMAL) & (kmax != 0u);
-        if (!go) break;
-        if (it >= cap) {
-            s.st = SCCBF_STATUS_INFEASIBLE;
-            break;
-        }
-        const int sel = 1023 - (int)(kmax & 0x3FFu);
-        pivot_onto_(s, s_at0[sel], s_at1[sel], s_bt[sel], true);  // broadcast reads
-    }
-    const int st = s.st;
-    const T w0 = s.w0, w1 = s.w1;
-    if (lane == 0 && live) store_result_(p, qp, QP_ONLY, st, w0, w1, e, ur0, ur1);
+    const Pivot<T> s = wave_active_set_<T>(M, lane, s_at0, s_at1, s_bt, bad);
+    if (lane == 0 && live) store_result_(p, qp, QP_ONLY, s.st, s.w0, s.w1, e, ur0, ur1);
 }
 
 // ------------------------------------- barrier value and partials only (no rows, no QP)

@@ -45,7 +45,13 @@ def random_case(rng, A, M):
             slots[m] = np.stack([cx, cy, rng.uniform(1.5, 4, A), rng.uniform(1.5, 4, A), rng.uniform(-3, 3, A),
                                  rng.uniform(-3, 3, A), rng.uniform(0.5, 1.5, A), np.zeros(A)], axis=1)
     obs = np.ascontiguousarray(slots.reshape(M, A, 2, 4).transpose(0, 2, 1, 3))
-    return state, u_ref, obs, kinds
+    # half of the ellipse and cone slots in their prepared forms (kinds 4 and 5: same obstacle, constants evaluated)
+    from sccav_cbf_amd import scenarios
+    wp = scenarios.prepared(dict(obs=obs, obs_type=kinds))
+    take = (rng.uniform(size=M) < 0.5) & ((kinds == 0) | (kinds == 1))
+    obs[take] = wp["obs"][take]
+    kinds = np.where(take, wp["obs_type"], kinds).astype(np.uint8)
+    return state, u_ref, np.ascontiguousarray(obs), kinds
 
 
 def main():
@@ -72,10 +78,8 @@ def main():
         lanes = int(rng.choice([0, 1, 2, 4, 8, 16, 64]))
         if lanes not in (0, 64) and M > 16 * lanes:
             lanes = 0
-        if M > 256 and dyn in ("dum", "sadbm"):
-            dyn = "dbm"
-        if dyn in ("dum", "sadbm"):     # these models run with 4 or 16 lanes per QP
-            lanes = lanes if lanes in (0, 16) or (lanes == 4 and M <= 64) else 0
+        if dyn in ("dum", "sadbm"):     # these models run with 4 or 16 lanes per QP or one wavefront
+            lanes = lanes if lanes in (0, 64) or (lanes == 16 and M <= 256) or (lanes == 4 and M <= 64) else 0
         sa_dt = float(rng.choice([0.02, 0.1]))
         sa_slip = np.stack([rng.uniform(-0.3, 0.3, A), rng.uniform(-0.3, 0.3, A)], axis=1)
         cone_beta = bool(rng.integers(0, 2))

@@ -175,3 +175,46 @@ def test_closed_loop_ticks_with_the_steer_rate_filter(oracle):
         loop.state.copy_(torch.from_numpy(s).to(dev))
         loop.slip.copy_(torch.from_numpy(slip).to(dev))
         loop.target_idx.copy_(torch.from_numpy(tgt).to(dev))
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("dyn", ["dum", "sadbm"])
+@pytest.mark.parametrize("M,lanes", [(300, 0), (24, 64), (1024, 64)])
+def test_one_wavefront_per_qp_for_the_other_models(oracle, dyn, M, lanes, dtype):
+    """More rows than sixteen lanes hold (and the same kernel forced on a short list): one wavefront per QP,
+    rows in LDS, for the unicycle-input and the steer-rate model."""
+    A, dt = 96, 0.05
+    base = scenarios.config4(A=A, nominal="uniform", seed=5)
+    reps = -(-M // 16)
+    rng = np.random.default_rng(M)
+    obs = np.concatenate([base["obs"]] * reps, axis=0)[:M].copy()
+    obs[:, 0, :, 0:2] += rng.normal(0, 6.0, (M, A, 2))            # the copies of an obstacle do not coincide
+    ty = np.tile(base["obs_type"], reps)[:M].copy()
+    u_ref = base["u_ref"].copy()
+    dcode = oracle.DYN_DUM if dyn == "dum" else oracle.DYN_SADBM
+    p = oracle.make_params(alpha=1.0, R=R_HALF.reshape(-1), dynamics=dcode)
+    f = _filter(lanes=lanes, dynamics=dyn)
+    dev = _dev()
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev).to(dtype)   # noqa: E731
+    if dyn == "dum":
+        uo, so, ro = oracle.solve_batch(p, base["state"], u_ref, obs, ty, want_rows=True)
+        ug, sg, rg = f.solve(tt(base["state"]), tt(u_ref), tt(obs), torch.from_numpy(ty).to(dev), want_rows=True)
+        un = u_ref
+    else:
+        slip = np.stack([rng.uniform(-0.2, 0.2, A), rng.uniform(-0.2, 0.2, A)], axis=1)
+        so_slip = slip.copy()
+        uo, so, ro = oracle.solve_sa_batch(p, dt, base["state"], so_slip, u_ref, obs, ty, want_rows=True)
+        sl = tt(slip)
+        ug, sg, rg = f.solve(tt(base["state"]), tt(u_ref), tt(obs), torch.from_numpy(ty).to(dev), want_rows=True,
+                             slip=sl, dt=dt)
+    torch.cuda.synchronize()
+    ug, sg, rg = ug.double().cpu().numpy(), sg.cpu().numpy(), rg.double().cpu().numpy()
+    assert (sg != so).sum() <= (0 if dtype == torch.float64 else 1)
+    tol = 1e-9 if dtype == torch.float64 else 1e-3
+    assert (np.abs(rg - ro) / (np.abs(ro).max(axis=2, keepdims=True) + 1.0)).max() <= tol
+    both = (sg == 0) & (so == 0) & (np.abs(uo[:, 1]) < 1.2)
+    scale = np.maximum(1.0, np.hypot(uo[:, 0], uo[:, 1]))
+    assert (np.abs(ug - uo).max(axis=1) / scale)[both].max(initial=0) <= (1e-8 if dtype == torch.float64 else 5e-3)
+    if dyn == "sadbm":
+        ok = sg == so
+        assert np.abs(sl.double().cpu().numpy() - so_slip)[ok].max() <= (1e-9 if dtype == torch.float64 else 1e-4)
