@@ -5,26 +5,45 @@ agent block shard_bounds(A, world, r) and runs the filter on it.  Collectives
 (torch.distributed: backend "nccl" = RCCL over xGMI on GPUs, "gloo" for CPU rehearsals)
 appear only at the edges: scatter of a batch assembled on one rank, all-gather of the
 controls.  gloo is only ever handed CPU tensors.
+
+Two ways to get a rank its shard:
+  local_batch   every rank makes its own agents from (seed, rank): no traffic at all (what a
+                Monte-Carlo campaign and bench.py do)
+  scatter       a batch assembled on one rank is cut into blocks and sent point to point, each block
+                once and at its own size; with align=64 the cuts fall on tile boundaries, so a rank's
+                slice of tiled obstacle slots (ceil(A/64), M, 2, 64, 4) is one contiguous block
 """
 import torch
 import torch.distributed as dist
 
+TILE = 64
 
-def shard_bounds(A, world, rank):
-    """[lo, hi) of rank's contiguous block; the first A % world ranks hold one more agent."""
-    base, rem = divmod(A, world)
+
+def shard_bounds(A, world, rank, align=1):
+    """[lo, hi) of rank's contiguous block.  align=1: the first A % world ranks hold one more agent.
+    align=64 (tiled obstacle slots): blocks of whole tiles, the first ranks hold one more tile and the
+    last block ends at A."""
+    units = (A + align - 1) // align
+    base, rem = divmod(units, world)
     lo = rank * base + min(rank, rem)
-    return lo, lo + base + (1 if rank < rem else 0)
+    hi = lo + base + (1 if rank < rem else 0)
+    return min(lo * align, A), min(hi * align, A)
 
 
 def shard_batch(batch, world, rank):
-    """Slice a full batch dict (state (A,4), u_ref (A,2), obs (M,2,A,4) or shared (M,2,4),
-    obs_type (M,) or (M,A)) down to the rank's block."""
+    """Slice a full batch dict (state (A,4), u_ref (A,2), obs planes (M,2,A,4), tiles
+    (ceil(A/64),M,2,64,4) or shared (M,2,4), obs_type (M,) or (M,A)) down to the rank's block; tiled
+    obstacle slots are cut on tile boundaries."""
     A = batch["state"].shape[0]
-    lo, hi = shard_bounds(A, world, rank)
-    out = {"state": batch["state"][lo:hi].contiguous(), "u_ref": batch["u_ref"][lo:hi].contiguous()}
     obs, ty = batch["obs"], batch["obs_type"]
-    out["obs"] = obs if obs.dim() == 3 else obs[:, :, lo:hi, :].contiguous()
+    lo, hi = shard_bounds(A, world, rank, align=TILE if obs.dim() == 5 else 1)
+    out = {"state": batch["state"][lo:hi].contiguous(), "u_ref": batch["u_ref"][lo:hi].contiguous()}
+    if obs.dim() == 3:
+        out["obs"] = obs
+    elif obs.dim() == 5:
+        out["obs"] = obs[(lo + TILE - 1) // TILE:(hi + TILE - 1) // TILE].contiguous()   # (an empty block: lo = hi = A)
+    else:
+        out["obs"] = obs[:, :, lo:hi, :].contiguous()
     out["obs_type"] = ty if ty.dim() == 1 else ty[:, lo:hi].contiguous()
     return out
 
@@ -47,36 +66,57 @@ class ShardedCBF:
         """Tensor as the backend wants it: host memory for gloo (synchronous copy)."""
         return t.cpu() if (_is_gloo(self.group) and t.is_cuda) else t
 
-    def scatter(self, batch, A, M, dtype, device, src=0, per_agent_types=False):
+    def local_batch(self, make, agents_per_rank, seed):
+        """This rank's own agents: make(A=agents_per_rank, seed=seed + rank) -> batch dict.  No
+        communication; ranks differ by their seed only."""
+        return make(A=agents_per_rank, seed=seed + self.rank)
+
+    def scatter(self, batch, A, M, dtype, device, src=0, per_agent_types=False, tiled=False):
         """Distribute a batch that lives on `src` (other ranks pass None); returns this rank's
-        shard on `device`.  Blocks are padded to equal length for the collective."""
+        shard on `device`.  Every block travels once, at its own size (no padding), point to point.
+        tiled: batch["obs"] is (ceil(A/64), M, 2, 64, 4) and the blocks are cut on tile boundaries."""
         world, rank = self.world, self.rank
-        chunk = (A + world - 1) // world
-        lo, hi = shard_bounds(A, world, rank)
-        n = hi - lo
+        align = TILE if tiled else 1
         cdev = torch.device("cpu") if _is_gloo(self.group) else device
 
-        def scatter_rows(full, tail_shape, dt, agent_dim):
-            # full: tensor with the agent axis at agent_dim (src only)
-            recv = torch.empty((chunk,) + tail_shape, dtype=dt, device=cdev)
-            parts = None
-            if rank == src:
-                moved = self._comm(full).movedim(agent_dim, 0)
-                parts = []
-                for r in range(world):
-                    a, b = shard_bounds(A, world, r)
-                    p = torch.zeros((chunk,) + tail_shape, dtype=dt, device=cdev)
-                    p[: b - a] = moved[a:b]
-                    parts.append(p)
-            dist.scatter(recv, parts, src=src, group=self.group)
-            return recv[:n].movedim(0, agent_dim).contiguous().to(device)
+        def parts(r):
+            lo, hi = shard_bounds(A, world, r, align)
+            n = hi - lo
+            shapes = [("state", (n, 4), dtype), ("u_ref", (n, 2), dtype),
+                      ("obs", ((n + TILE - 1) // TILE, M, 2, TILE, 4) if tiled else (M, 2, n, 4), dtype)]
+            if per_agent_types:
+                shapes.append(("obs_type", (M, n), torch.uint8))
+            return lo, hi, shapes
 
-        out = {"state": scatter_rows(batch["state"] if rank == src else None, (4,), dtype, 0),
-               "u_ref": scatter_rows(batch["u_ref"] if rank == src else None, (2,), dtype, 0),
-               "obs": scatter_rows(batch["obs"] if rank == src else None, (M, 2, 4), dtype, 2)}
-        if per_agent_types:
-            out["obs_type"] = scatter_rows(batch["obs_type"] if rank == src else None, (M,), torch.uint8, 1)
+        def cut(name, lo, hi):
+            t = batch[name]
+            if name == "obs":
+                return t[(lo + TILE - 1) // TILE:(hi + TILE - 1) // TILE] if tiled else t[:, :, lo:hi, :]
+            if name == "obs_type":
+                return t[:, lo:hi]
+            return t[lo:hi]
+
+        out = {}
+        if rank == src:
+            pending = []
+            for r in range(world):
+                lo, hi, shapes = parts(r)
+                for name, shape, _ in shapes:
+                    piece = cut(name, lo, hi).contiguous()
+                    if r == src:
+                        out[name] = piece.to(device)
+                    elif piece.numel():
+                        pending.append(dist.isend(self._comm(piece), dst=r, group=self.group))
+            for req in pending:
+                req.wait()
         else:
+            _, _, shapes = parts(rank)
+            for name, shape, dt in shapes:
+                buf = torch.empty(shape, dtype=dt, device=cdev)
+                if buf.numel():
+                    dist.recv(buf, src=src, group=self.group)
+                out[name] = buf.to(device)
+        if not per_agent_types:
             ty = self._comm(batch["obs_type"]).clone() if rank == src else torch.empty((M,), dtype=torch.uint8, device=cdev)
             dist.broadcast(ty, src=src, group=self.group)
             out["obs_type"] = ty.to(device)
@@ -85,10 +125,11 @@ class ShardedCBF:
     def solve_local(self, shard):
         return self.solve(shard["state"], shard["u_ref"], shard["obs"], shard["obs_type"])
 
-    def all_gather(self, u_local, status_local, A):
-        """Controls and status of the whole batch on every rank."""
+    def all_gather(self, u_local, status_local, A, align=1):
+        """Controls and status of the whole batch on every rank (align as in the scatter)."""
         world = self.world
-        chunk = (A + world - 1) // world
+        sizes = [b - a for a, b in (shard_bounds(A, world, r, align) for r in range(world))]
+        chunk = max(sizes) if sizes else 0
         dev = u_local.device
         n = u_local.shape[0]
         up = torch.zeros((chunk, 2), dtype=u_local.dtype, device=dev)
@@ -99,9 +140,6 @@ class ShardedCBF:
         sg = torch.empty((world * chunk,), dtype=sp.dtype, device=sp.device)
         dist.all_gather_into_tensor(ug, up, group=self.group)
         dist.all_gather_into_tensor(sg, sp, group=self.group)
-        us, ss = [], []
-        for r in range(world):
-            a, b = shard_bounds(A, world, r)
-            us.append(ug[r * chunk: r * chunk + (b - a)])
-            ss.append(sg[r * chunk: r * chunk + (b - a)])
+        us = [ug[r * chunk: r * chunk + sizes[r]] for r in range(world)]
+        ss = [sg[r * chunk: r * chunk + sizes[r]] for r in range(world)]
         return torch.cat(us).to(dev), torch.cat(ss).to(dev)

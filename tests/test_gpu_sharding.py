@@ -24,7 +24,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, A, ret):
+def _worker(rank, world, port, A, tiled, ret):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -39,14 +39,23 @@ def _worker(rank, world, port, A, ret):
             w = scenarios.config4(A=A, nominal="uniform")
             batch = {k: torch.from_numpy(v) for k, v in w.items()}
             batch = {k: (v.float() if v.dtype.is_floating_point else v) for k, v in batch.items()}
+        from sccav_cbf_amd.batched import planes_to_tiled
+        planes = None
+        if rank == 0 and tiled:      # the layout the benchmark uses: a rank's tiles are one contiguous block
+            planes = batch["obs"]
+            batch["obs"] = planes_to_tiled(planes)
         sh = ShardedCBF(flt.solve)
-        shard = sh.scatter(batch, A, M, torch.float32, dev)
-        lo, hi = shard_bounds(A, world, rank)
-        assert shard["state"].is_cuda and shard["obs"].shape == (M, 2, hi - lo, 4)
+        align = 64 if tiled else 1
+        shard = sh.scatter(batch, A, M, torch.float32, dev, tiled=tiled)
+        lo, hi = shard_bounds(A, world, rank, align)
+        assert shard["state"].is_cuda
+        assert shard["obs"].shape == (((hi - lo + 63) // 64, M, 2, 64, 4) if tiled else (M, 2, hi - lo, 4))
         u, st = sh.solve_local(shard)
         torch.cuda.synchronize()
-        ug, sg = sh.all_gather(u, st, A)
+        ug, sg = sh.all_gather(u, st, A, align=align)
         if rank == 0:
+            if tiled:
+                batch["obs"] = planes
             full = {k: v.to(dev) for k, v in batch.items()}
             uf, sf = flt.solve(full["state"], full["u_ref"], full["obs"], full["obs_type"])
             torch.cuda.synchronize()
@@ -57,11 +66,12 @@ def _worker(rank, world, port, A, ret):
         dist.destroy_process_group()
 
 
-def test_two_ranks_on_the_gpu_scatter_solve_gather():
+@pytest.mark.parametrize("tiled", [False, True], ids=["planes", "tiles"])
+def test_two_ranks_on_the_gpu_scatter_solve_gather(tiled):
     world, A = 2, 5001
     mgr = mp.Manager()
     ret = mgr.dict()
-    ctx = mp.spawn(_worker, args=(world, _free_port(), A, ret), nprocs=world, join=False)
+    ctx = mp.spawn(_worker, args=(world, _free_port(), A, tiled, ret), nprocs=world, join=False)
     t0 = time.time()
     while not ctx.join(timeout=5):
         if time.time() - t0 > 150:

@@ -25,6 +25,17 @@ def test_shard_bounds_cover_and_balance():
             assert max(sizes) - min(sizes) <= 1
 
 
+def test_tile_aligned_bounds():
+    for A in (1, 63, 64, 65, 1000, 65536, 65537):
+        for world in (1, 2, 3, 8):
+            b = [shard_bounds(A, world, r, align=64) for r in range(world)]
+            assert b[0][0] == 0 and b[-1][1] == A
+            assert all(b[i][1] == b[i + 1][0] for i in range(world - 1))
+            assert all(lo % 64 == 0 for lo, _ in b if lo < A)
+            tiles = [(hi - lo + 63) // 64 for lo, hi in b]
+            assert max(tiles) - min(tiles) <= 1
+
+
 def test_shard_batch_slices():
     w = scenarios.config4(A=101, nominal="uniform")
     t = {k: torch.from_numpy(v) for k, v in w.items()}
@@ -43,7 +54,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, A, per_agent, ret):
+def _worker(rank, world, port, A, per_agent, tiled, ret):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ["OMP_NUM_THREADS"] = "1"
@@ -66,12 +77,25 @@ def _worker(rank, world, port, A, per_agent, ret):
                 ty[::3, ::5] = 255
                 w["obs_type"] = np.ascontiguousarray(ty)
             batch = {k: torch.from_numpy(v) for k, v in w.items()}
+        from sccav_cbf_amd.batched import planes_to_tiled
+        planes = None
+        if rank == 0:
+            planes = batch["obs"]
+            if tiled:
+                batch["obs"] = planes_to_tiled(planes)
         sh = ShardedCBF(solve)
-        shard = sh.scatter(batch, A, M, torch.float64, torch.device("cpu"), per_agent_types=per_agent)
-        lo, hi = shard_bounds(A, world, rank)
-        assert shard["state"].shape == (hi - lo, 4) and shard["obs"].shape == (M, 2, hi - lo, 4)
+        align = 64 if tiled else 1
+        shard = sh.scatter(batch, A, M, torch.float64, torch.device("cpu"), per_agent_types=per_agent, tiled=tiled)
+        lo, hi = shard_bounds(A, world, rank, align)
+        assert shard["state"].shape == (hi - lo, 4)
+        if tiled:    # a rank's tiles are one contiguous block of the batch; back to planes for the oracle
+            assert shard["obs"].shape == ((hi - lo + 63) // 64, M, 2, 64, 4) and shard["obs"].is_contiguous()
+            shard["obs"] = shard["obs"].permute(1, 2, 0, 3, 4).reshape(M, 2, -1, 4)[:, :, :hi - lo].contiguous()
+        assert shard["obs"].shape == (M, 2, hi - lo, 4)
         u, st = sh.solve_local(shard)
-        ug, sg = sh.all_gather(u, st, A)
+        ug, sg = sh.all_gather(u, st, A, align=align)
+        if rank == 0:
+            batch["obs"] = planes
         if rank == 0:
             uf, sf = solve(batch["state"], batch["u_ref"], batch["obs"], batch["obs_type"])
             ret["equal"] = bool(torch.equal(ug, uf) and torch.equal(sg, sf))
@@ -80,12 +104,25 @@ def _worker(rank, world, port, A, per_agent, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("A,per_agent", [(1000, False), (1001, True)])
-def test_two_rank_gloo_scatter_solve_gather(A, per_agent):
+@pytest.mark.parametrize("A,per_agent,tiled", [(1000, False, False), (1001, True, False), (1001, False, True),
+                                              (130, True, True), (40, False, True)])
+def test_two_rank_gloo_scatter_solve_gather(A, per_agent, tiled):
     from oracle import oracle as orc
     orc.build()
     world = 2
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), A, per_agent, ret), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), A, per_agent, tiled, ret), nprocs=world, join=True)
     assert ret["n"] == A and ret["equal"]
+
+
+def test_local_batches_differ_by_rank_only():
+    """Every rank makes its own agents from (seed, rank): the no-traffic alternative to the scatter."""
+    class _Fake(ShardedCBF):
+        def __init__(self, rank):
+            self.rank, self.world, self.group, self.solve = rank, 2, None, None
+    a = _Fake(0).local_batch(lambda A, seed: scenarios.config4(A=A, seed=seed, nominal="uniform"), 50, 9)
+    b = _Fake(1).local_batch(lambda A, seed: scenarios.config4(A=A, seed=seed, nominal="uniform"), 50, 9)
+    a2 = _Fake(0).local_batch(lambda A, seed: scenarios.config4(A=A, seed=seed, nominal="uniform"), 50, 9)
+    assert a["state"].shape == (50, 4) and not np.array_equal(a["state"], b["state"])
+    assert np.array_equal(a["state"], a2["state"]) and np.array_equal(a["obs"], a2["obs"])
