@@ -105,8 +105,7 @@ extern "C" {
 /* error codes */
 #define SCCBF_OK 0
 #define SCCBF_ERR_ARG (-1)         /* NULL pointer / negative size / A >= 2^31 / bad enum or flags */
-#define SCCBF_ERR_ROWS (-2)        /* M above SCCBF_MAX_ROWS, or above the limit stated at the entry point
-                                      (64 slots for the rollout) */
+#define SCCBF_ERR_ROWS (-2)        /* M above SCCBF_MAX_ROWS */
 #define SCCBF_ERR_WEIGHT (-3)      /* R not symmetric positive definite */
 #define SCCBF_ERR_LAUNCH (-4)      /* hipLaunch failed */
 #define SCCBF_ERR_VARIANT (-5)     /* lanes_per_qp cannot hold M rows */
@@ -367,7 +366,8 @@ void sccbf_default_rollout_params(sccbf_rollout_params* p);
  *   pid_state    T[A][2]   in/out or NULL, as in sccbf_nominal_*
  *   slip         T[A][2]   in/out, SCCBF_DYN_SADBM only (else unused, may be NULL): beta, beta_ref_last
  *                          as in sccbf_solve_sa_*
- *   obs, obs_type          as in sccbf_solve_* (planes or tiles; not the shared table), 1 <= M <= 64;
+ *   obs, obs_type          as in sccbf_solve_* (planes or tiles; not the shared table), M >= 1: up to 64
+ *                          slots four lanes serve an agent, beyond that a whole wavefront does;
  *                          read once: moving obstacles advance in registers, obs is not written
  *   h_min        T[A]      optional: least barrier value over all ticks and slots
  *   n_active     i32[A]    optional: ticks on which the filter changed the nominal input

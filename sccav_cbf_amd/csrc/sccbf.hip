@@ -353,14 +353,14 @@ int vehicle_step_impl(int64_t A, T* state, const T* u, double lr, double lf, dou
     return hipGetLastError() == hipSuccess ? SCCBF_OK : SCCBF_ERR_LAUNCH;
 }
 
-template <typename T, int RPL>
+template <typename T, int RPL, int G>
 int launch_rollout(const RArgs<T>& r, bool ext, hipStream_t s)
 {
-    const long long per_block = kBlock / kNomLanes;
+    const long long per_block = kBlock / G;
     const long long blocks = (r.f.A + per_block - 1) / per_block;
     if (blocks > 0x7fffffffLL) return SCCBF_ERR_ARG;
-    if (ext) hipLaunchKernelGGL((k_rollout<T, RPL, true>), dim3((unsigned)blocks), dim3(kBlock), 0, s, r);
-    else hipLaunchKernelGGL((k_rollout<T, RPL, false>), dim3((unsigned)blocks), dim3(kBlock), 0, s, r);
+    if (ext) hipLaunchKernelGGL((k_rollout<T, RPL, true, G>), dim3((unsigned)blocks), dim3(kBlock), 0, s, r);
+    else hipLaunchKernelGGL((k_rollout<T, RPL, false, G>), dim3((unsigned)blocks), dim3(kBlock), 0, s, r);
     return hipGetLastError() == hipSuccess ? SCCBF_OK : SCCBF_ERR_LAUNCH;
 }
 
@@ -374,7 +374,6 @@ int rollout_impl(const sccbf_params* sp, const sccbf_nominal_params* np, const s
     RArgs<T> r;
     int rc = fill_args<T>(sp, A, M, r.f);
     if (rc != SCCBF_OK) return rc;
-    if (M > 16 * kNomLanes) return SCCBF_ERR_ROWS;
     if (N < 0 || M < 1 || rp->ticks < 0 || !(rp->dt > 0.0) || !(rp->max_steer >= 0.0)) return SCCBF_ERR_ARG;
     if (rp->motion != SCCBF_MOTION_STATIC && rp->motion != SCCBF_MOTION_CONSTANT_VELOCITY &&
         rp->motion != SCCBF_MOTION_SEEKER)
@@ -404,12 +403,20 @@ int rollout_impl(const sccbf_params* sp, const sccbf_nominal_params* np, const s
     r.h_min = h_min; r.n_active = n_active; r.n_infeasible = n_infeasible; r.trace = trace;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const bool ext = sadbm || sp->dynamics == SCCBF_DYN_DUM;
-    const int rpl = (M + kNomLanes - 1) / kNomLanes;
-    if (rpl <= 1) return launch_rollout<T, 1>(r, ext, s);
-    if (rpl <= 2) return launch_rollout<T, 2>(r, ext, s);
-    if (rpl <= 4) return launch_rollout<T, 4>(r, ext, s);
-    if (rpl <= 8) return launch_rollout<T, 8>(r, ext, s);
-    return launch_rollout<T, 16>(r, ext, s);
+    // four lanes per agent hold up to 64 slots, a whole wavefront per agent up to 1024
+    if (M <= 16 * kNomLanes) {
+        const int rpl = (M + kNomLanes - 1) / kNomLanes;
+        if (rpl <= 1) return launch_rollout<T, 1, kNomLanes>(r, ext, s);
+        if (rpl <= 2) return launch_rollout<T, 2, kNomLanes>(r, ext, s);
+        if (rpl <= 4) return launch_rollout<T, 4, kNomLanes>(r, ext, s);
+        if (rpl <= 8) return launch_rollout<T, 8, kNomLanes>(r, ext, s);
+        return launch_rollout<T, 16, kNomLanes>(r, ext, s);
+    }
+    const int rpl = (M + 63) / 64;
+    if (rpl <= 2) return launch_rollout<T, 2, 64>(r, ext, s);
+    if (rpl <= 4) return launch_rollout<T, 4, 64>(r, ext, s);
+    if (rpl <= 8) return launch_rollout<T, 8, 64>(r, ext, s);
+    return launch_rollout<T, 16, 64>(r, ext, s);
 }
 
 template <typename T>

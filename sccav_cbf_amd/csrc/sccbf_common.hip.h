@@ -207,7 +207,10 @@ __device__ inline unsigned viol_bits(double v, double thr)
 __device__ inline unsigned viol_bits_pos(float v) { return __float_as_uint(v); }
 __device__ inline unsigned viol_bits_pos(double v) { return __float_as_uint(fmaxf((float)v, 1.17549435e-38f)); }
 // does the winning key stand for a violation above thr?
-__device__ inline bool viol_key_above(int key, float thr) { return __uint_as_float((unsigned)key & ~0xFFu) > thr; }
-__device__ inline bool viol_key_above(int key, double) { return key > 0xFF; }
+__device__ inline bool viol_key_above(int key, float thr, unsigned idx_mask = 0xFFu)
+{
+    return __uint_as_float((unsigned)key & ~idx_mask) > thr;
+}
+__device__ inline bool viol_key_above(int key, double, unsigned idx_mask = 0xFFu) { return key > (int)idx_mask; }
 
 }  // namespace

@@ -103,9 +103,12 @@ __device__ inline Pivot<T> active_set_(int M, int g, const T (&at0)[RPL], const 
     // take the most violated row, move the optimum onto it
     Pivot<T> s;
     s.reset(bad ? SCCBF_STATUS_NONFINITE : SCCBF_STATUS_OPTIMAL);
-    unsigned idx[RPL];  // 255 - row index: ties in violation go to the lowest index
+    // the row index rides in the low bits of the key: 8 bits for up to 256 rows per QP, else 10
+    constexpr unsigned kIdxMask = G * RPL > 256 ? 0x3FFu : 0xFFu;
+    static_assert(G * RPL <= 1024, "row index field");
+    unsigned idx[RPL];  // mask - row index: ties in violation go to the lowest index
 #pragma unroll
-    for (int r = 0; r < RPL; ++r) idx[r] = (unsigned)(255 - (r * G + g));
+    for (int r = 0; r < RPL; ++r) idx[r] = kIdxMask - (unsigned)(r * G + g);
     const int cap = kCapPerRow * M + kCapBase;
     // One step: find the most violated row of the group, move the optimum onto it.
     // Returns false (wave-uniform) once no group of the wave has work left.
@@ -120,11 +123,11 @@ __device__ inline Pivot<T> active_set_(int M, int g, const T (&at0)[RPL], const 
 #pragma unroll
         for (int r = 0; r < RPL; ++r) {
             const T viol = first ? bt[r] : bt[r] - at0[r] * s.w0 - at1[r] * s.w1;
-            key[r] = (int)((viol_bits(viol, thr) & ~0xFFu) | idx[r]);
+            key[r] = (int)((viol_bits(viol, thr) & ~kIdxMask) | idx[r]);
             kbest = (r == 0 || key[r] > kbest) ? key[r] : kbest;  // always the key of a real slot
         }
         const int kmax = group_imax<G>(kbest);
-        const bool go = (s.st == SCCBF_STATUS_OPTIMAL) & viol_key_above(kmax, thr);
+        const bool go = (s.st == SCCBF_STATUS_OPTIMAL) & viol_key_above(kmax, thr, kIdxMask);
         if (!__any(go)) return false;  // every group of the wave is done
         if (it >= cap) {               // no convergence: rows numerically inconsistent
             s.st = go ? SCCBF_STATUS_INFEASIBLE : s.st;
@@ -132,7 +135,7 @@ __device__ inline Pivot<T> active_set_(int M, int g, const T (&at0)[RPL], const 
         }
         T c0 = T(0), c1 = T(0), cb = T(0);
         if (LDS_PICK) {
-            const int at = qslot + 255 - (kmax & 0xFF);
+            const int at = qslot + (int)(kIdxMask - ((unsigned)kmax & kIdxMask));
             c0 = s_rows[at];
             c1 = s_rows[plane + at];
             cb = s_rows[2 * plane + at];

@@ -427,14 +427,17 @@ __device__ inline void seek_slot_(int type, typename VT<T>::v4& oa, typename VT<
 // EXT = true: the models of k_group_ext (DUM: u = (a, omega), omega_ref = v tan(delta_ref) / L, unicycle
 // step; SADBM: u = (a, delta) in and out, slip state per agent, every cone takes the agent's beta, step
 // update_com with the filter's delta).
-template <typename T, int RPL, bool EXT>
+// G lanes hold an agent's slots and solve its QP: 4 (up to 64 slots) or a whole wavefront (up to 1024);
+// the nearest way-point is always searched by groups of four lanes (with G = 64 the sixteen groups of
+// a wavefront do the same search and find the same answer).
+template <typename T, int RPL, bool EXT, int G = kNomLanes>
 __global__ __launch_bounds__(kBlock)
-__attribute__((amdgpu_waves_per_eu((sizeof(T) == 4 && RPL <= 4) ? SCCBF_ROLLOUT_WAVES : 1, SCCBF_ROLLOUT_WAVES)))
+__attribute__((amdgpu_waves_per_eu((sizeof(T) == 4 && RPL <= 4 && G == kNomLanes) ? SCCBF_ROLLOUT_WAVES : 1, SCCBF_ROLLOUT_WAVES)))
 void k_rollout(const RArgs<T> a)
 {
     using v4 = typename VT<T>::v4;
     using v2 = typename VT<T>::v2;
-    constexpr int G = kNomLanes;
+    static_assert(G == kNomLanes || G == 64, "lanes per agent");
     constexpr int kMpad = G * RPL + 1;
     constexpr int kPlane = (kBlock / G) * kMpad;
     __shared__ CoursePass<T> c;
@@ -443,6 +446,7 @@ void k_rollout(const RArgs<T> a)
     const KArgs<T>& p = a.f;
     const NArgs<T>& np = a.n;
     const int g = threadIdx.x % G;
+    const int gn = threadIdx.x % kNomLanes;  // lane of the nominal controller's group of four
     long long ag = (long long)blockIdx.x * (kBlock / G) + threadIdx.x / G;
     const bool live = ag < p.A;
     if (!live) ag = p.A - 1;  // stays for the barrier; stores are masked
@@ -488,7 +492,7 @@ void k_rollout(const RArgs<T> a)
             if (one_pass) {
                 const T lx = c.x[(lt / kSub) * kSubStride + lt % kSub], ly = c.y[(lt / kSub) * kSubStride + lt % kSub];
                 lim = len2_(fx - lx, fy - ly);
-                nearest_in_pass_(c, fx, fy, g, 0, (np.N + kSub - 1) / kSub, lim, ai, best, bi);
+                nearest_in_pass_(c, fx, fy, gn, 0, (np.N + kSub - 1) / kSub, lim, ai, best, bi);
             } else {
                 const v2 wl = *reinterpret_cast<const v2*>(traj4 + lt);
                 lim = len2_(fx - wl.x, fy - wl.y);
@@ -497,7 +501,7 @@ void k_rollout(const RArgs<T> a)
                     __syncthreads();
                     stage_course_<T, kBlock>(c, traj4, base, n);
                     __syncthreads();
-                    nearest_in_pass_(c, fx, fy, g, base, (n + kSub - 1) / kSub, lim, ai, best, bi);
+                    nearest_in_pass_(c, fx, fy, gn, base, (n + kSub - 1) / kSub, lim, ai, best, bi);
                 }
             }
             bi = group_nearest_(best, bi, np.N);
@@ -572,8 +576,8 @@ void k_rollout(const RArgs<T> a)
         __builtin_amdgcn_wave_barrier();
         const Pivot<T> s = active_set_<T, G, RPL, true>(p.M, g, at0, at1, bt, s_rows, kPlane, qslot, bad);
         __builtin_amdgcn_wave_barrier();  // the table is rewritten next tick
-        hm = min_(hm, __shfl_xor(hm, 1, 64));
-        hm = min_(hm, __shfl_xor(hm, 2, 64));
+#pragma unroll
+        for (int m = 1; m < G; m *= 2) hm = min_(hm, __shfl_xor(hm, m, 64));
         h_min = min_(h_min, hm);
         n_act += (s.st == SCCBF_STATUS_OPTIMAL) & ((s.w0 != T(0)) | (s.w1 != T(0)));
         n_inf += s.st == SCCBF_STATUS_INFEASIBLE;

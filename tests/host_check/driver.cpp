@@ -40,7 +40,7 @@ int main()
     expect(sccbf_solve_step_f32(0, 0.5, 0.1, 0, 4, 0, 0, 0, 0, 0, 0, 0, 0), -1, "solve_step null params");
     rp.ticks = 3;
     expect(sccbf_rollout_f32(&p, &np, &rp, 0, 4, 10, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0), 0, "rollout empty");
-    expect(sccbf_rollout_f64(&p, &np, &rp, 4, 65, 10, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0), -2, "rollout slots");
+    expect(sccbf_rollout_f64(&p, &np, &rp, 4, 1025, 10, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0), -2, "rollout slots");
     for (int m = -1; m <= 4; ++m) { rp.motion = m; sccbf_rollout_f32(&p, &np, &rp, 4, 4, 10, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0); }
     for (int d = 0; d <= 3; ++d) { p.dynamics = d; sccbf_rollout_f64(&p, &np, &rp, 4, 4, 3000, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0); }
     p.dynamics = 0; rp.motion = 0;

@@ -104,7 +104,7 @@ def test_rollout_argument_validation(lib):
     assert call(0, 4, 100) == 0                      # empty batch
     assert call(8, 4, 100) == -1                     # null data
     assert call(8, 4, 2049) == -1                    # a long course is fine (staged pass by pass): null data
-    assert call(8, 65, 100) == -2                    # more slots than four lanes hold
+    assert call(8, 65, 100) == -1 and call(8, 1025, 100) == -2   # a wavefront per agent beyond 64 slots: null data
     assert call(8, 0, 100) == -1 and call(8, 4, -1) == -1
     assert call(0, 4, 0) == 0                        # no course: the nominal input is zero
     r.motion = 9

@@ -564,11 +564,13 @@ def _model_loop(dyn, A, M, seed, dtype, N=None, tiled=False):
 
 
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
-@pytest.mark.parametrize("dyn,M,tiled", [("kbm", 12, False), ("dum", 16, True), ("sadbm", 9, False), ("sadbm", 40, True)])
+@pytest.mark.parametrize("dyn,M,tiled", [("kbm", 12, False), ("dum", 16, True), ("sadbm", 9, False), ("sadbm", 40, True),
+                                         ("dbm", 100, True), ("dbm", 300, False), ("sadbm", 130, False),
+                                         ("dum", 1000, True)])   # beyond 64 slots: one wavefront per agent
 def test_rollout_of_every_model_equals_its_ticks(dtype, dyn, M, tiled):
     """sccbf_rollout_* for the kinematic, unicycle-input and steer-rate models against ClosedLoop.tick
     (nominal -> the model's solve entry -> the model's vehicle step) launched tick by tick."""
-    A, T = 300, 20
+    A, T = (300, 20) if M <= 64 else (40, 8)
     make = _model_loop(dyn, A, M, 90 + M, dtype, tiled=tiled)
     la = make()
     tr = []
