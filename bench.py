@@ -52,7 +52,7 @@ def c4_batch(agents, seed, slots):
     return scenarios.prepared(w) if slots == "prepared" else w
 
 
-def make_ring(rank, device, n=RING, agents=AGENTS, layout="tiles", slots="prepared"):
+def make_ring(rank, device, n, agents=AGENTS, layout="tiles", slots="prepared"):
     from sccav_cbf_amd.batched import planes_to_tiled
     ring = []
     for b in range(n):
@@ -301,6 +301,8 @@ def launcher(args, argv):
 
 # -------------------------------------------------------------------------------- a rank
 def worker(args):
+    global RING
+    RING = args.ring
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -357,7 +359,7 @@ def worker(args):
         # every step reads a batch that is not touched again for RING - 1 steps: say so
         flt = BatchedCBF(alpha=1.0, lr=1.45, lf=1.45, R=np.diag([0.5, 0.5]), lanes_per_qp=args.lanes,
                          streamed_obs=not args.no_stream_hint)
-        ring = make_ring(rank, device, agents=A, layout=args.layout, slots=args.slots)
+        ring = make_ring(rank, device, RING, agents=A, layout=args.layout, slots=args.slots)
 
         def step(i):
             b = ring[i % RING]
@@ -386,21 +388,22 @@ def worker(args):
     else:
         stream = torch.cuda.Stream(device)
         with torch.cuda.stream(stream):
-            for i in range(RING):
+            glen = max(RING, 10)   # launches per captured walk
+            for i in range(glen):
                 step(i)
             torch.cuda.synchronize()
             if not args.no_graph:
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph, stream=stream):
-                    for i in range(RING):
+                    for i in range(glen):
                         step(i)
 
             def run(k):
                 done = 0
                 if graph is not None:
-                    for _ in range(k // RING):
+                    for _ in range(k // glen):
                         graph.replay()
-                    done = (k // RING) * RING
+                    done = (k // glen) * glen
                 for i in range(done, k):
                     step(i)
 
@@ -408,9 +411,9 @@ def worker(args):
             # warm-up gives it: untimed walks over the ring first, then the W warm-up steps.
             t_ramp = time.perf_counter()
             while (time.perf_counter() - t_ramp) * 1e3 < args.ramp_ms:
-                run(10 * RING)
+                run(10 * glen)
                 torch.cuda.synchronize()
-                ramp_steps += 10 * RING
+                ramp_steps += 10 * glen
             run(args.warmup)
             barrier()
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -479,7 +482,7 @@ def worker(args):
                        "obs_layout": layout_name,
                        "obs_slots": "prepared (kinds 4, 5: 1/a^2, 1/b^2, cos, sin and the cone's obstacle velocity "
                                     "stored in the slot)" if args.slots == "prepared" else "as written (kinds 0, 1)",
-                       "launch": "eager" if graph is None else "hipGraph of %d launches" % RING,
+                       "launch": "eager" if graph is None else "hipGraph of %d launches" % max(RING, 10),
                        "clock_ramp_steps_before_warmup": ramp_steps},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": _profile_json("traffic.json"),
@@ -537,6 +540,10 @@ def main():
                          "reference's objects hold them; 8 scalars per slot either way")
     ap.add_argument("--no-stream-hint", action="store_true",
                     help="do not tell the library that each step's obstacle slots are read once (SCCBF_FLAG_OBS_STREAMED)")
+    ap.add_argument("--ring", type=int, default=RING,
+                    help="distinct batches the steps walk over (default 10: more than the Infinity Cache holds, every "
+                         "step streams from HBM; 1: the same batch every step, served from the Infinity Cache, which "
+                         "shows what the arithmetic alone costs)")
     ap.add_argument("--no-large", action="store_true", help="skip the extra 1M-agent measurement (N=1 only)")
     ap.add_argument("--large-only", action="store_true",
                     help="only the 2^20-agent measurement (with --steps < 1000: that many walks over its ring of 3)")

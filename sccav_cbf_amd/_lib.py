@@ -66,6 +66,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    alt = os.environ.get("SCCBF_LIBRARY")   # another build of the same sources (measurements of build options)
+    if alt:
+        return _bind(C.CDLL(alt))
     if not os.path.exists(LIB):
         raise SccbfError(
             "libsccbf.so not found at %s: build it with `python -m sccav_cbf_amd._build` "
@@ -76,7 +79,11 @@ def load():
             raise SccbfError("libsccbf.so is older than its sources (csrc/, include/sccbf.h): rebuild with "
                              "`python -m sccav_cbf_amd._build`")
         _build.build_library()
-    L = C.CDLL(LIB)
+    return _bind(C.CDLL(LIB))
+
+
+def _bind(L):
+    global _lib
     vp = C.c_void_p
     L.sccbf_version.restype = C.c_int
     if L.sccbf_version() != ABI_VERSION:

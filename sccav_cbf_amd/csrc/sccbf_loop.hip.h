@@ -432,7 +432,8 @@ __device__ inline void seek_slot_(int type, typename VT<T>::v4& oa, typename VT<
 // a wavefront do the same search and find the same answer).
 template <typename T, int RPL, bool EXT, int G = kNomLanes>
 __global__ __launch_bounds__(kBlock)
-__attribute__((amdgpu_waves_per_eu((sizeof(T) == 4 && RPL <= 4 && G == kNomLanes) ? SCCBF_ROLLOUT_WAVES : 1, SCCBF_ROLLOUT_WAVES)))
+__attribute__((amdgpu_waves_per_eu(
+    (RPL <= 4 && G == kNomLanes) ? (sizeof(T) == 4 ? SCCBF_ROLLOUT_WAVES : SCCBF_ROLLOUT_WAVES_F64) : 1, SCCBF_ROLLOUT_WAVES)))
 void k_rollout(const RArgs<T> a)
 {
     using v4 = typename VT<T>::v4;
