@@ -166,7 +166,7 @@ def _time_graph(walk, stream, n_per_walk, reps, graph=True):
     return e0.elapsed_time(e1) / (reps * n_per_walk)   # ms per launch
 
 
-def large_batch(flt, device, layout, slots, agents=1 << 20, n=3, reps=60, graph=True):
+def large_batch(flt, device, layout, slots, agents=1 << 20, n=3, reps=200, graph=True):
     """The same kernel on 2^20 agents per launch (not part of `value`): at that size a launch is
     no longer dominated by its start-up and tail.  The ring re-uses one C4 batch rotated by whole
     tiles: 3 x 575 MB, more than twice the Infinity Cache."""
@@ -339,7 +339,7 @@ def worker(args):
         from sccav_cbf_amd.batched import BatchedCBF
         flt = BatchedCBF(alpha=1.0, lr=1.45, lf=1.45, R=np.diag([0.5, 0.5]), lanes_per_qp=args.lanes,
                          streamed_obs=not args.no_stream_hint)
-        out = large_batch(flt, device, args.layout, args.slots, reps=args.steps if args.steps < 1000 else 60,
+        out = large_batch(flt, device, args.layout, args.slots, reps=args.steps if args.steps < 1000 else 200,
                           graph=not args.no_graph)
         out["large_only"] = True
         print(json.dumps(out), flush=True)
