@@ -8,8 +8,8 @@
 //                       keeps RPL rows in registers; cross-lane steps are DPP moves
 //                       inside the G-lane group, the winning row of a step comes back
 //                       from an LDS copy of the rows by index.  G = 1 is one thread per QP.
-//   k_wave<T, WPB>      one 64-lane wavefront per QP, rows staged in LDS, any M;
-//                       the most violated row is found by a wave-wide max.
+//   k_wave<T, WPB, G>   G = 16, 32 or 64 lanes per QP (64 = one wavefront per QP), rows staged
+//                       in LDS only, any M; the most violated row is found by a max over the group.
 //
 // The QP (reference cbf/cbf.py:182-213 hands it to cvxopt.solvers.cp) is solved
 // exactly: in w = Lc^T (u - u_nom), R = Lc Lc^T, it is the least-norm point of the
@@ -67,17 +67,18 @@ int fill_args(const sccbf_params* sp, int64_t A, int32_t M, KArgs<T>& k)
     return SCCBF_OK;
 }
 
-// lanes-per-QP when the caller leaves the choice to the library (measured on MI355X with
-// 16 rows: 4 lanes from 32768 QPs up to 1M, 8 around 8192-16384, 16 below; the
-// one-wavefront-per-QP kernel only when the rows do not fit 16 lanes x 16 registers)
+// lanes-per-QP when the caller leaves the choice to the library (measured on MI355X: with 16 rows
+// 4 lanes from 32768 QPs up to 1M, 8 around 8192-16384, 16 below; with 32 ... 128 rows and 65536 QPs
+// 8 lanes; from there on the kernels that keep the rows in LDS only are faster than 16 lanes x 16
+// registers: 98 against 116 us at 200 rows, 116 against 130 at 256)
 int auto_lanes(int64_t A, int M)
 {
+    if (M > 128) return 64;  // rows in LDS only; wave_lanes() then picks the group
     int g;
-    if (A >= (1 << 15)) g = 4;
+    if (A >= (1 << 15)) g = M <= 16 ? 4 : 8;
     else if (A >= (1 << 13)) g = 8;
     else g = 16;
     while (g < 16 && M > 16 * g) g *= 2;  // keep at most 16 rows per lane
-    if (M > 16 * g) return 64;
     return g;
 }
 
@@ -116,19 +117,73 @@ int launch_group_rpl(const KArgs<T>& k, hipStream_t s)
     return SCCBF_ERR_VARIANT;
 }
 
-template <typename T, bool QP_ONLY>
+// The kernels that keep the rows in LDS only: G lanes per QP, QPB QPs per workgroup = the agents that share a
+// 128-byte line of an obstacle plane or a few of those, never a part of one (a line fetched by two
+// workgroups is fetched into the L2 of two XCDs).  G = 16: 16 QPs (256 threads), G = 32: 8 QPs (256 threads),
+// G = 64: 8 QPs in fp32 (512 threads), 4 in fp64 (256 threads).  A workgroup's row tables may take the whole
+// 160 KB of a CU's LDS.
+constexpr size_t kLdsPerCu = 160 * 1024;
+template <typename T, int G> struct WaveShape {
+    static constexpr int kQpb = G == 16 ? 16 : (G == 32 ? 8 : (sizeof(T) == 4 ? 8 : 4));
+};
+
+template <typename T> size_t wave_lds(int M, int qpb) { return wave_lds_bytes<T>(M, qpb); }
+
+// lanes per QP when the library chooses (measured at 65536 agents, fp32, 257 ... 1024 rows): 32 while four
+// of its workgroups fit a CU (16 wavefronts), else a wavefront per QP, whose workgroups have twice the
+// wavefronts for the same tables
+template <typename T> int wave_lanes(int M)
+{
+    if (wave_lds<T>(M, WaveShape<T, 32>::kQpb) * 4 <= kLdsPerCu) return 32;
+    return 64;
+}
+
+// more than 64 KB of dynamic LDS has to be granted per kernel, once per device
+template <auto Kernel> bool grant_lds(size_t lds)
+{
+    if (lds <= 64 * 1024) return true;
+    if (lds > kLdsPerCu) return false;
+    static bool done[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    if (!done[dev]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(Kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)kLdsPerCu) != hipSuccess)
+            return false;
+        done[dev] = true;
+    }
+    return true;
+}
+
+// grid of a kernel whose workgroups take QPB agents each; PAIRED: see wave_first_agent()
+template <int QPB, bool PAIRED> long long wave_blocks(long long A)
+{
+    if (!PAIRED) return (A + QPB - 1) / QPB;
+    const long long groups = (A + 2 * QPB - 1) / (2 * QPB);  // of 2 QPB agents: a line's worth
+    return (groups + 7) / 8 * 16;
+}
+
+// two workgroups of a line's worth of tables (eight fp32 agents, four fp64) no longer fit a CU: half of
+// them per workgroup, paired on an XCD
+template <typename T> bool wave_paired(int M) { return wave_lds<T>(M, WaveShape<T, 64>::kQpb) * 2 > kLdsPerCu; }
+
+template <typename T, bool QP_ONLY, int G, int QPB, bool PAIRED>
+int launch_wave_shape(const KArgs<T>& k, hipStream_t s)
+{
+    const size_t lds = wave_lds<T>(k.M, QPB);
+    const long long blocks = wave_blocks<QPB, PAIRED>(k.A);
+    if (blocks > 0x7fffffffLL) return SCCBF_ERR_ARG;
+    if (!grant_lds<k_wave<T, QPB, QP_ONLY, G, PAIRED>>(lds)) return SCCBF_ERR_VARIANT;
+    hipLaunchKernelGGL((k_wave<T, QPB, QP_ONLY, G, PAIRED>), dim3((unsigned)blocks), dim3(QPB * G), lds, s, k);
+    return hipGetLastError() == hipSuccess ? SCCBF_OK : SCCBF_ERR_LAUNCH;
+}
+
+template <typename T, bool QP_ONLY, int G>
 int launch_wave(const KArgs<T>& k, hipStream_t s)
 {
-    const size_t per_wave = (size_t)3 * k.M * sizeof(T);
-    if (per_wave * 4 <= 48 * 1024) {
-        const long long blocks = (k.A + 3) / 4;
-        if (blocks > 0x7fffffffLL) return SCCBF_ERR_ARG;
-        hipLaunchKernelGGL((k_wave<T, 4, QP_ONLY>), dim3((unsigned)blocks), dim3(256), per_wave * 4, s, k);
-    } else {
-        if (k.A > 0x7fffffffLL) return SCCBF_ERR_ARG;
-        hipLaunchKernelGGL((k_wave<T, 1, QP_ONLY>), dim3((unsigned)k.A), dim3(64), per_wave, s, k);
-    }
-    return hipGetLastError() == hipSuccess ? SCCBF_OK : SCCBF_ERR_LAUNCH;
+    constexpr int kQpb = WaveShape<T, G>::kQpb;
+    if (G == 64 && wave_paired<T>(k.M)) return launch_wave_shape<T, QP_ONLY, G, (G == 64 ? kQpb / 2 : kQpb), G == 64>(k, s);
+    return launch_wave_shape<T, QP_ONLY, G, kQpb, false>(k, s);
 }
 
 template <typename T, bool QP_ONLY>
@@ -144,13 +199,15 @@ int dispatch(const sccbf_params* sp, KArgs<T>& k, void* stream)
     }
     int lanes = sp->lanes_per_qp;
     if (lanes == 0) lanes = auto_lanes(k.A, k.M);
+    if (lanes == 64 && sp->lanes_per_qp == 0) lanes = wave_lanes<T>(k.M);
     switch (lanes) {
     case 1: return launch_group_rpl<T, QP_ONLY, 1>(k, s);
     case 2: return launch_group_rpl<T, QP_ONLY, 2>(k, s);
     case 4: return launch_group_rpl<T, QP_ONLY, 4>(k, s);
     case 8: return launch_group_rpl<T, QP_ONLY, 8>(k, s);
-    case 16: return launch_group_rpl<T, QP_ONLY, 16>(k, s);
-    case 64: return launch_wave<T, QP_ONLY>(k, s);
+    case 16: return k.M <= 256 ? launch_group_rpl<T, QP_ONLY, 16>(k, s) : launch_wave<T, QP_ONLY, 16>(k, s);
+    case 32: return launch_wave<T, QP_ONLY, 32>(k, s);
+    case 64: return launch_wave<T, QP_ONLY, 64>(k, s);
     default: return SCCBF_ERR_VARIANT;
     }
 }
@@ -173,18 +230,23 @@ int launch_ext_rpl(const KArgs<T>& k, const XArgs<T>& x, hipStream_t s)
     return hipGetLastError() == hipSuccess ? SCCBF_OK : SCCBF_ERR_LAUNCH;
 }
 
-template <typename T>
+template <typename T, int G, int QPB, bool PAIRED>
+int launch_wave_ext_shape(const KArgs<T>& k, const XArgs<T>& x, hipStream_t s)
+{
+    const size_t lds = wave_lds<T>(k.M, QPB);
+    const long long blocks = wave_blocks<QPB, PAIRED>(k.A);
+    if (blocks > 0x7fffffffLL) return SCCBF_ERR_ARG;
+    if (!grant_lds<k_wave_ext<T, QPB, G, PAIRED>>(lds)) return SCCBF_ERR_VARIANT;
+    hipLaunchKernelGGL((k_wave_ext<T, QPB, G, PAIRED>), dim3((unsigned)blocks), dim3(QPB * G), lds, s, k, x);
+    return hipGetLastError() == hipSuccess ? SCCBF_OK : SCCBF_ERR_LAUNCH;
+}
+
+template <typename T, int G>
 int launch_wave_ext(const KArgs<T>& k, const XArgs<T>& x, hipStream_t s)
 {
-    const size_t per_wave = (size_t)3 * k.M * sizeof(T);
-    if (per_wave * 4 <= 48 * 1024) {
-        const long long blocks = (k.A + 3) / 4;
-        if (blocks > 0x7fffffffLL) return SCCBF_ERR_ARG;
-        hipLaunchKernelGGL((k_wave_ext<T, 4>), dim3((unsigned)blocks), dim3(256), per_wave * 4, s, k, x);
-    } else {
-        hipLaunchKernelGGL((k_wave_ext<T, 1>), dim3((unsigned)k.A), dim3(64), per_wave, s, k, x);
-    }
-    return hipGetLastError() == hipSuccess ? SCCBF_OK : SCCBF_ERR_LAUNCH;
+    constexpr int kQpb = WaveShape<T, G>::kQpb;
+    if (G == 64 && wave_paired<T>(k.M)) return launch_wave_ext_shape<T, G, (G == 64 ? kQpb / 2 : kQpb), G == 64>(k, x, s);
+    return launch_wave_ext_shape<T, G, kQpb, false>(k, x, s);
 }
 
 template <typename T>
@@ -192,10 +254,11 @@ int dispatch_ext(const sccbf_params* sp, const KArgs<T>& k, const XArgs<T>& x, v
 {
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     int lanes = sp->lanes_per_qp;
-    if (lanes == 0) lanes = k.M > 256 ? 64 : ((k.A >= (1 << 13) && k.M <= 64) ? 4 : 16);
+    if (lanes == 0) lanes = k.M > 128 ? wave_lanes<T>(k.M) : ((k.A >= (1 << 13) && k.M <= 64) ? 4 : 16);
     if (lanes == 4 && k.M <= 64) return launch_ext_rpl<T, 4>(k, x, s);
-    if (lanes == 16 && k.M <= 256) return launch_ext_rpl<T, 16>(k, x, s);
-    if (lanes == 64) return launch_wave_ext<T>(k, x, s);
+    if (lanes == 16) return k.M <= 256 ? launch_ext_rpl<T, 16>(k, x, s) : launch_wave_ext<T, 16>(k, x, s);
+    if (lanes == 32) return launch_wave_ext<T, 32>(k, x, s);
+    if (lanes == 64) return launch_wave_ext<T, 64>(k, x, s);
     return SCCBF_ERR_VARIANT;
 }
 

@@ -175,35 +175,35 @@ __global__ __launch_bounds__(kBlock) void k_group_ext(const KArgs<T> p, const XA
     ext_epilogue_(p, x, qp, q, s.st, s.w0, s.w1);
 }
 
-// One wavefront per QP, rows staged in LDS: any M up to SCCBF_MAX_ROWS (k_wave for these models).
-template <typename T, int WPB>
-__global__ __launch_bounds__(WPB * 64) void k_wave_ext(const KArgs<T> p, const XArgs<T> x)
+// G lanes per QP, rows staged in LDS only: any M up to SCCBF_MAX_ROWS (k_wave for these models, the same
+// two thread layouts).
+template <typename T, int QPB, int G, bool PAIRED = false>
+__global__ __launch_bounds__(QPB * G) void k_wave_ext(const KArgs<T> p, const XArgs<T> x)
 {
     using v4 = typename VT<T>::v4;
     using v2 = typename VT<T>::v2;
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    const int lane = threadIdx.x & 63;
-    const int wv = threadIdx.x >> 6;
+    static_assert(QPB * G % 64 == 0, "whole wavefronts");
     const int M = p.M;
-    T* s_at0 = reinterpret_cast<T*>(smem_raw) + (size_t)wv * 3 * M;
-    T* s_at1 = s_at0 + M;
-    T* s_bt = s_at1 + M;
+    const WaveTables<T> tab(smem_raw, M, QPB);
+    const int stride = wave_table_stride(M);
+    const int qa = (int)(threadIdx.x % QPB), rsub = (int)(threadIdx.x / QPB);  // forming rows
+    const int qs = (int)(threadIdx.x / G), g = (int)(threadIdx.x % G);         // solving
 
-    long long qp = (long long)blockIdx.x * WPB + wv;
+    long long qp = wave_first_agent<QPB, PAIRED>() + qa;
     const bool live = qp < p.A;
-    if (!live) qp = p.A - 1;  // keep the wave for the block barrier; its stores are masked
+    if (!live) qp = p.A - 1;  // the thread stays for the barriers; its stores are masked
+    if (threadIdx.x < QPB) tab.bad[threadIdx.x] = 0;
 
-    const bool type_pa = (p.flags & SCCBF_FLAG_TYPE_PER_AGENT) != 0;
-    const v4* obs4 = reinterpret_cast<const v4*>(p.obs);
-    const ObsAddr oad = obs_addr_(p, qp);
     ExtEgo<T> q;
     ext_prologue_(p, x, qp, reinterpret_cast<const v4*>(p.state)[qp], reinterpret_cast<const v2*>(p.u_ref)[qp], q);
     int bad = q.bad;
-    for (int m = lane; m < M; m += 64) {
-        const long long i0 = oad.at(m);
-        const v4 oa = obs4[i0];
-        const v4 ob = obs4[i0 + oad.half];
-        const int ty = type_pa ? p.obs_type[(long long)m * p.A + qp] : p.obs_type[m];
+    __syncthreads();
+
+    T* r_at0 = tab.rows + (size_t)qa * stride;
+    T* r_at1 = r_at0 + M;
+    T* r_bt = r_at1 + M;
+    staged_rows_<T, G, false>(p, qp, rsub, [&](int m, const v4& oa, const v4& ob, int ty) {
         T o[8] = {oa.x, oa.y, oa.z, oa.w, ob.x, ob.y, ob.z, ob.w};
         T a0, a1, b, h;
         ext_slot_row_(ty, o, q.e, p, q.sadbm, q.cone_beta_state, q.sl.x, q.cthb, q.sthb, q.sb, a0, a1, b, h);
@@ -211,14 +211,21 @@ __global__ __launch_bounds__(WPB * 64) void k_wave_ext(const KArgs<T> p, const X
         bad |= !(finite_(a0) && finite_(a1) && finite_(b));
         T t0, t1, tb;
         to_wspace_(a0, a1, b, q.e, p, t0, t1, tb);
-        s_at0[m] = t0;
-        s_at1[m] = t1;
-        s_bt[m] = tb;
-    }
-    bad = __any(bad);
+        r_at0[m] = t0;
+        r_at1[m] = t1;
+        r_bt[m] = tb;
+    });
+    if (bad) tab.bad[qa] = 1;
     __syncthreads();
-    const Pivot<T> s = wave_active_set_<T>(M, lane, s_at0, s_at1, s_bt, bad);
-    if (lane == 0 && live) ext_epilogue_(p, x, qp, q, s.st, s.w0, s.w1);
+    const T* s_at0 = tab.rows + (size_t)qs * stride;
+    const Pivot<T> s = wave_active_set_<T, G>(M, g, s_at0, s_at0 + M, s_at0 + 2 * M, tab.bad[qs]);
+    if (g == 0) {
+        tab.answer[2 * qs] = s.w0;
+        tab.answer[2 * qs + 1] = s.w1;
+        tab.status[qs] = s.st;
+    }
+    __syncthreads();
+    if (rsub == 0 && live) ext_epilogue_(p, x, qp, q, tab.status[qa], tab.answer[2 * qa], tab.answer[2 * qa + 1]);
 }
 
 }  // namespace

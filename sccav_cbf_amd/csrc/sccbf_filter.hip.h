@@ -215,12 +215,13 @@ __global__ __launch_bounds__(kBlock) void k_group(long long A, const T* obs, con
     group_solve_<T, G, RPL, QP_ONLY>(p, qp, g, L);
 }
 
-// ------------------------------------------ one wavefront per QP, rows staged in LDS
-// The active-set iteration of one wavefront on the M rows it has staged in LDS: every lane scans
-// rows lane, lane + 64, ..., the most violated row comes from a wave-wide max, the pivot reads it
-// by index (broadcast reads).
-template <typename T>
-__device__ inline Pivot<T> wave_active_set_(int M, int lane, const T* s_at0, const T* s_at1, const T* s_bt, int bad)
+// ------------------------------------------ rows staged in LDS only: any M up to SCCBF_MAX_ROWS
+// The active-set iteration of a group of G lanes (16, 32 or the whole wavefront) on the M rows it has
+// staged in LDS: every lane scans rows g, g + G, ..., the most violated row comes from a max over the
+// group, the pivot reads it by index (broadcast reads).  The trip count is wave-uniform; the groups
+// of a wavefront commit under `go`.
+template <typename T, int G>
+__device__ inline Pivot<T> wave_active_set_(int M, int g, const T* s_at0, const T* s_at1, const T* s_bt, int bad)
 {
     Pivot<T> s;
     s.reset(bad ? SCCBF_STATUS_NONFINITE : SCCBF_STATUS_OPTIMAL);
@@ -228,75 +229,177 @@ __device__ inline Pivot<T> wave_active_set_(int M, int lane, const T* s_at0, con
     for (int it = 0;; ++it) {  // wave-uniform loop
         const T thr = Lim<T>::viol_tol * (abs_(s.w0) + abs_(s.w1)) + Lim<T>::tiny_n2;
         unsigned kbest = 0u;
-        for (int m = lane; m < M; m += 64) {
+        for (int m = g; m < M; m += G) {
             const T viol = s_bt[m] - (s_at0[m] * s.w0 + s_at1[m] * s.w1);
             const unsigned key = viol > thr ? ((viol_bits_pos(viol) & ~0x3FFu) | (unsigned)(1023 - m)) : 0u;
             kbest = key > kbest ? key : kbest;
         }
-        const unsigned kmax = group_umax<64>(kbest);
+        const unsigned kmax = group_umax<G>(kbest);
         const bool go = (s.st == SCCBF_STATUS_OPTIMAL) & (kmax != 0u);
-        if (!go) break;
+        if (!__any(go)) break;  // every group of the wavefront is done
         if (it >= cap) {
-            s.st = SCCBF_STATUS_INFEASIBLE;
+            s.st = go ? SCCBF_STATUS_INFEASIBLE : s.st;
             break;
         }
-        const int sel = 1023 - (int)(kmax & 0x3FFu);
-        pivot_onto_(s, s_at0[sel], s_at1[sel], s_bt[sel], true);  // broadcast reads
+        const int sel = go ? 1023 - (int)(kmax & 0x3FFu) : 0;
+        pivot_onto_(s, s_at0[sel], s_at1[sel], s_bt[sel], go);  // broadcast reads
     }
     return s;
 }
 
-template <typename T, int WPB, bool QP_ONLY>
-__global__ __launch_bounds__(WPB * 64) void k_wave(const KArgs<T> p)
+// LDS words between the row tables of two QPs of a workgroup: odd, so that the groups of a wavefront
+// scan different banks
+__host__ __device__ inline int wave_table_stride(int M) { return (3 * M) | 1; }
+
+// The slots of a lane (g, g + G, ...) come kWaveBatch at a time, and the next batch is on its way while the
+// rows of the current one are formed: with the few wavefronts per CU that the row tables leave room for, a
+// wavefront has to overlap its own loads and arithmetic.  row(m, oa, ob, ty) forms and stores row m.
+constexpr int kWaveBatch = 4;
+template <typename T> struct SlotBatch {
+    typename VT<T>::v4 oa[kWaveBatch], ob[kWaveBatch];
+    int ty[kWaveBatch];
+};
+
+template <typename T, int G, bool QP_ONLY>
+__device__ inline void batch_load_(const KArgs<T>& p, const ObsAddr& oad, long long qp, bool type_pa, int m0,
+                                   SlotBatch<T>& B)
+{
+    using v4 = typename VT<T>::v4;
+    const v4* obs4 = reinterpret_cast<const v4*>(p.obs);
+#pragma unroll
+    for (int k = 0; k < kWaveBatch; ++k) {
+        const int m = min(m0 + k * G, p.M - 1);  // past the end: a slot that exists, its row is dropped
+        if (QP_ONLY) {
+            B.oa[k] = obs4[(long long)m * p.A + qp];
+        } else {
+            const long long at = oad.at(m);
+            B.oa[k] = obs4[at];
+            B.ob[k] = obs4[at + oad.half];
+            B.ty[k] = type_pa ? p.obs_type[(long long)m * p.A + qp] : p.obs_type[m];
+        }
+    }
+}
+
+template <typename T, int G, bool QP_ONLY, typename RowFn>
+__device__ inline void staged_rows_(const KArgs<T>& p, long long qp, int g, RowFn row)
+{
+    const bool type_pa = (p.flags & SCCBF_FLAG_TYPE_PER_AGENT) != 0;
+    const ObsAddr oad = obs_addr_(p, qp);
+    constexpr int kStep = kWaveBatch * G;
+    const int M = p.M;
+    SlotBatch<T> b0, b1;
+    batch_load_<T, G, QP_ONLY>(p, oad, qp, type_pa, g, b0);
+    for (int base = 0; base < M; base += 2 * kStep) {  // wave-uniform
+        if (base + kStep < M) batch_load_<T, G, QP_ONLY>(p, oad, qp, type_pa, base + kStep + g, b1);
+#pragma unroll
+        for (int k = 0; k < kWaveBatch; ++k) {
+            const int m = base + k * G + g;
+            if (m < M) row(m, b0.oa[k], b0.ob[k], b0.ty[k]);
+        }
+        if (base + kStep >= M) break;
+        if (base + 2 * kStep < M) batch_load_<T, G, QP_ONLY>(p, oad, qp, type_pa, base + 2 * kStep + g, b0);
+#pragma unroll
+        for (int k = 0; k < kWaveBatch; ++k) {
+            const int m = base + kStep + k * G + g;
+            if (m < M) row(m, b1.oa[k], b1.ob[k], b1.ty[k]);
+        }
+    }
+}
+
+// G lanes per QP in the active-set iteration (G = 16, 32 or 64: a whole wavefront), QPB QPs per workgroup:
+// at least the agents that share a 128-byte line of an obstacle plane (eight in fp32, four in fp64).
+// While the rows are formed the threads are laid out the other way round, agents fastest: thread t forms
+// rows t / QPB, t / QPB + G, ... of agent t % QPB, so a load instruction reads whole lines (QPB agents of a
+// few consecutive slots), consecutive slots of one kind keep the kind branch uniform, and every row goes into
+// its agent's table in LDS.  After the workgroup barrier thread t scans the table of agent t / G with the
+// other G - 1 lanes of its group; the answer goes back through LDS to the thread that holds that agent's
+// state (t < QPB), which stores it.  A CU should hold at least two workgroups: while one iterates, the other
+// loads; one alone leaves the memory idle for a quarter of the time.
+template <typename T> struct WaveTables {
+    T* rows;      // QPB tables of wave_table_stride(M) values: at0[M], at1[M], bt[M]
+    T* answer;    // QPB x (w0, w1)
+    int* status;  // QPB
+    int* bad;     // QPB
+    __device__ WaveTables(unsigned char* raw, int M, int qpb)
+    {
+        rows = reinterpret_cast<T*>(raw);
+        answer = rows + (size_t)qpb * wave_table_stride(M);
+        status = reinterpret_cast<int*>(answer + 2 * qpb);
+        bad = status + qpb;
+    }
+};
+template <typename T> __host__ __device__ inline size_t wave_lds_bytes(int M, int qpb)
+{
+    return ((size_t)qpb * wave_table_stride(M) + 2 * qpb) * sizeof(T) + 2 * qpb * sizeof(int);
+}
+
+// First agent of a workgroup.  PAIRED: the workgroup takes half of the agents that share a line, and the
+// workgroup with the other half is the one eight further on in the grid: workgroups are dealt to the XCDs in
+// turn, so the two sit on the same XCD, start about together, and the second finds the line in that XCD's L2.
+// (Placement is not promised: if it differs, the line is fetched twice and nothing else changes.)  The grid
+// is a multiple of 16 workgroups.
+template <int QPB, bool PAIRED> __device__ inline long long wave_first_agent()
+{
+    if (!PAIRED) return (long long)blockIdx.x * QPB;
+    const unsigned xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+    return ((long long)(slot >> 1) * 8 + xcd) * (2 * QPB) + (slot & 1u) * QPB;
+}
+
+template <typename T, int QPB, bool QP_ONLY, int G, bool PAIRED = false>
+__global__ __launch_bounds__(QPB * G) void k_wave(const KArgs<T> p)
 {
     using v4 = typename VT<T>::v4;
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    const int lane = threadIdx.x & 63;
-    const int wv = threadIdx.x >> 6;
+    static_assert(QPB * G % 64 == 0, "whole wavefronts");
+    constexpr int RS = G;  // rows of an agent formed side by side
     const int M = p.M;
-    T* s_at0 = reinterpret_cast<T*>(smem_raw) + (size_t)wv * 3 * M;
-    T* s_at1 = s_at0 + M;
-    T* s_bt = s_at1 + M;
+    const WaveTables<T> tab(smem_raw, M, QPB);
+    const int stride = wave_table_stride(M);
+    const int qa = (int)(threadIdx.x % QPB), rsub = (int)(threadIdx.x / QPB);  // forming rows
+    const int qs = (int)(threadIdx.x / G), g = (int)(threadIdx.x % G);         // solving
 
-    long long qp = (long long)blockIdx.x * WPB + wv;
+    long long qp = wave_first_agent<QPB, PAIRED>() + qa;
     const bool live = qp < p.A;
-    if (!live) qp = p.A - 1;  // keep the wave for the block barrier; its stores are masked
-
-    const bool type_pa = (p.flags & SCCBF_FLAG_TYPE_PER_AGENT) != 0;
-    const v4* obs4 = reinterpret_cast<const v4*>(p.obs);
-    const ObsAddr oad = obs_addr_(p, qp);
+    if (!live) qp = p.A - 1;  // the thread stays for the barriers; its stores are masked
+    if (threadIdx.x < QPB) tab.bad[threadIdx.x] = 0;
 
     Ego<T> e;
     T ur0, ur1;
     int bad;
     load_ego_(p, qp, QP_ONLY, e, ur0, ur1, bad);
+    __syncthreads();
 
-    for (int m = lane; m < M; m += 64) {
+    T* r_at0 = tab.rows + (size_t)qa * stride;
+    T* r_at1 = r_at0 + M;
+    T* r_bt = r_at1 + M;
+    staged_rows_<T, RS, QP_ONLY>(p, qp, rsub, [&](int m, const v4& oa, const v4& ob, int ty) {
         T a0, a1, b, h;
         if (QP_ONLY) {
-            const v4 rw = obs4[(long long)m * p.A + qp];
-            a0 = rw.x; a1 = rw.y; b = rw.z; h = T(0);
+            a0 = oa.x; a1 = oa.y; b = oa.z; h = T(0);
         } else {
-            const long long i0 = oad.at(m);
-            const v4 oa = obs4[i0];
-            const v4 ob = obs4[i0 + oad.half];
-            const int ty = type_pa ? p.obs_type[(long long)m * p.A + qp] : p.obs_type[m];
             const T o[8] = {oa.x, oa.y, oa.z, oa.w, ob.x, ob.y, ob.z, ob.w};
             slot_row_(ty, o, e, p, a0, a1, b, h);
-            if (p.rows_out && live)
-                reinterpret_cast<v4*>(p.rows_out)[(long long)m * p.A + qp] = v4{a0, a1, b, h};
+            if (p.rows_out && live) reinterpret_cast<v4*>(p.rows_out)[(long long)m * p.A + qp] = v4{a0, a1, b, h};
         }
         bad |= !(finite_(a0) && finite_(a1) && finite_(b));
         T t0, t1, tb;
         to_wspace_(a0, a1, b, e, p, t0, t1, tb);
-        s_at0[m] = t0;
-        s_at1[m] = t1;
-        s_bt[m] = tb;
-    }
-    bad = __any(bad);
+        r_at0[m] = t0;
+        r_at1[m] = t1;
+        r_bt[m] = tb;
+    });
+    if (bad) tab.bad[qa] = 1;
     __syncthreads();
-    const Pivot<T> s = wave_active_set_<T>(M, lane, s_at0, s_at1, s_bt, bad);
-    if (lane == 0 && live) store_result_(p, qp, QP_ONLY, s.st, s.w0, s.w1, e, ur0, ur1);
+    const T* s_at0 = tab.rows + (size_t)qs * stride;
+    const Pivot<T> s = wave_active_set_<T, G>(M, g, s_at0, s_at0 + M, s_at0 + 2 * M, tab.bad[qs]);
+    if (g == 0) {
+        tab.answer[2 * qs] = s.w0;
+        tab.answer[2 * qs + 1] = s.w1;
+        tab.status[qs] = s.st;
+    }
+    __syncthreads();
+    if (rsub == 0 && live)
+        store_result_(p, qp, QP_ONLY, tab.status[qa], tab.answer[2 * qa], tab.answer[2 * qa + 1], e, ur0, ur1);
 }
 
 // ------------------------------------- barrier value and partials only (no rows, no QP)

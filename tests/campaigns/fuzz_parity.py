@@ -75,11 +75,11 @@ def main():
         slip = bool(rng.integers(0, 2))
         per_agent = bool(rng.integers(0, 2))
         tiled = bool(rng.integers(0, 2))
-        lanes = int(rng.choice([0, 1, 2, 4, 8, 16, 64]))
-        if lanes not in (0, 64) and M > 16 * lanes:
+        lanes = int(rng.choice([0, 1, 2, 4, 8, 16, 32, 64]))
+        if lanes not in (0, 16, 32, 64) and M > 16 * lanes:
             lanes = 0
-        if dyn in ("dum", "sadbm"):     # these models run with 4 or 16 lanes per QP or one wavefront
-            lanes = lanes if lanes in (0, 64) or (lanes == 16 and M <= 256) or (lanes == 4 and M <= 64) else 0
+        if dyn in ("dum", "sadbm"):     # these models run with 4 lanes per QP (up to 64 rows), 16, 32 or 64
+            lanes = lanes if lanes in (0, 16, 32, 64) or (lanes == 4 and M <= 64) else 0
         sa_dt = float(rng.choice([0.02, 0.1]))
         sa_slip = np.stack([rng.uniform(-0.3, 0.3, A), rng.uniform(-0.3, 0.3, A)], axis=1)
         cone_beta = bool(rng.integers(0, 2))

@@ -179,10 +179,10 @@ def test_closed_loop_ticks_with_the_steer_rate_filter(oracle):
 
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
 @pytest.mark.parametrize("dyn", ["dum", "sadbm"])
-@pytest.mark.parametrize("M,lanes", [(300, 0), (24, 64), (1024, 64)])
+@pytest.mark.parametrize("M,lanes", [(300, 0), (24, 64), (1024, 64), (24, 32), (300, 16), (700, 0), (1024, 0)])
 def test_one_wavefront_per_qp_for_the_other_models(oracle, dyn, M, lanes, dtype):
-    """More rows than sixteen lanes hold (and the same kernel forced on a short list): one wavefront per QP,
-    rows in LDS, for the unicycle-input and the steer-rate model."""
+    """More rows than sixteen lanes hold (and the same kernel forced on a short list): 16 or 32 lanes or one
+    wavefront per QP, rows in LDS only, for the unicycle-input and the steer-rate model."""
     A, dt = 96, 0.05
     base = scenarios.config4(A=A, nominal="uniform", seed=5)
     reps = -(-M // 16)

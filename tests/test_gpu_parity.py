@@ -20,7 +20,7 @@ from tests import parity  # noqa: E402
 pytestmark = pytest.mark.gpu
 
 R_HALF = np.diag([0.5, 0.5])
-ALL_LANES = (0, 1, 2, 4, 8, 16, 64)
+ALL_LANES = (0, 1, 2, 4, 8, 16, 32, 64)
 
 
 def _dev():
@@ -120,7 +120,7 @@ SCENARIOS = {
 def test_solve_matches_oracle(oracle, name, dtype, lanes):
     w = SCENARIOS[name]()
     M = w["obs"].shape[0]
-    if lanes not in (0, 64) and M > 16 * lanes:
+    if lanes not in (0, 32, 64) and M > 16 * lanes:
         pytest.skip("this variant holds at most 16 rows per lane")
     uo, so, ro = _orc_solve(oracle, w)
     ug, sg, rg = _gpu_solve(w, dtype, lanes)
@@ -249,7 +249,7 @@ def test_impossible_row_behind_a_far_optimum(oracle, lanes, dtype, b2):
 def test_row_counts_and_ragged_batches(oracle, lanes, M):
     """Every row count around the register-tile boundaries; batch sizes that do not fill
     a wavefront or a workgroup; per-agent kinds with empty slots."""
-    if lanes not in (0, 64) and M > 16 * lanes:
+    if lanes not in (0, 32, 64) and M > 16 * lanes:
         pytest.skip("this variant holds at most 16 rows per lane")
     for A in (1, 3, 63, 65, 257):
         rng = np.random.default_rng(1000 + 7 * M + A)
@@ -286,7 +286,7 @@ def test_tiled_obstacle_layout(oracle, lanes, dtype):
     every kernel variant, batch sizes with a partial last tile included, and the oracle's answer."""
     from sccav_cbf_amd.batched import pack_obs, pack_obs_tiled, planes_to_tiled
     for A, M in ((1, 3), (63, 16), (64, 8), (65, 16), (1000, 16), (4097, 5), (130, 33)):
-        if lanes not in (0, 64) and M > 16 * lanes:
+        if lanes not in (0, 32, 64) and M > 16 * lanes:
             continue
         w = scenarios.monte_carlo(A, (M + 1) // 2, M // 2, 4242 + A, nominal="uniform")
         t = _to_dev(w, dtype)
@@ -340,14 +340,38 @@ def test_nonfinite_inputs_are_flagged(oracle):
             assert np.allclose(ug[so == 2], w["u_ref"][so == 2], equal_nan=True)
 
 
-def test_maximum_row_count(oracle):
-    """M = SCCBF_MAX_ROWS through the one-wavefront-per-QP kernel (rows in LDS)."""
-    M, A = _lib.MAX_ROWS, 9
-    w = scenarios.monte_carlo(A, M // 2, M // 2, 77, nominal="uniform")
-    w["obs"][:, 0, :, 0] += 400.0            # push obstacles away so the set stays feasible
-    uo, so, _ = _orc_solve(oracle, w)
-    ug, sg = _gpu_solve(w, torch.float64, 0, want_rows=False)
-    assert (sg == so).all() and np.abs(ug - uo).max() <= 1e-8 * (1 + np.abs(uo).max())
+def _many_rows(A, M, seed):
+    """The 16-slot scene of configuration 4 repeated up to M slots: copy k of an obstacle stands 10 k ... 10 k + 10 m
+    farther from the agent along the line of sight, so the feasible share stays that of 16 rows."""
+    base = scenarios.config4(A=A, nominal="uniform", seed=seed)
+    reps = -(-M // 16)
+    rng = np.random.default_rng(seed)
+    obs = np.concatenate([base["obs"]] * reps, axis=0)[:M].copy()
+    los = obs[:, 0, :, 0:2] - base["state"][None, :, 0:2]
+    los /= np.maximum(np.linalg.norm(los, axis=2, keepdims=True), 1e-3)
+    far = (np.arange(M) // 16)[:, None, None] * 10.0
+    obs[:, 0, :, 0:2] += los * (far + 10.0 * rng.uniform(size=(M, 1, 1)) * (far > 0))
+    return dict(state=base["state"], u_ref=base["u_ref"], obs=obs, obs_type=np.tile(base["obs_type"], reps)[:M].copy())
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("M,lanes", [(_lib.MAX_ROWS, 0), (800, 32), (_lib.MAX_ROWS, 64), (400, 16), (257, 16),
+                                     (300, 0), (700, 0), (129, 0), (900, 0)])
+def test_rows_in_lds_only_up_to_the_maximum_row_count(oracle, M, lanes, dtype):
+    """More rows than the register-resident kernels take, up to M = SCCBF_MAX_ROWS: rows staged in LDS only,
+    16 or 32 lanes or a whole wavefront per QP; batches that end inside a workgroup and inside a pair of them."""
+    for A in (9, 333):
+        w = _many_rows(A, M, 77 + A)
+        uo, so, ro = _orc_solve(oracle, w)
+        ug, sg = _gpu_solve(w, dtype, lanes, want_rows=False)
+        _check(ug, sg, uo, so, ro, w["u_ref"], dtype)
+
+
+def test_beyond_the_maximum_row_count_is_refused():
+    M = _lib.MAX_ROWS
+    w = scenarios.monte_carlo(3, M // 2, M // 2, 77, nominal="uniform")
+    with pytest.raises(_lib.SccbfError):     # sixteen fp64 tables of 1024 rows are more LDS than a CU has
+        _gpu_solve(w, torch.float64, 16, want_rows=False)
     f = _filter()
     t = _to_dev(scenarios.monte_carlo(2, M // 2 + 1, M // 2, 1, nominal="uniform"), torch.float64)
     with pytest.raises(_lib.SccbfError):

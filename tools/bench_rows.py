@@ -22,6 +22,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--agents", type=int, default=65536)
     ap.add_argument("--rows", default="16,64,257,1024")
+    ap.add_argument("--lanes", default="0", help="lanes_per_qp values to try (0: the library's choice)")
+    ap.add_argument("--models", default="dbm,kbm,dum,sadbm")
+    ap.add_argument("--sorted", action="store_true", help="slots grouped by kind instead of 8 + 8 repeated")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     A = args.agents
@@ -43,24 +46,32 @@ def main():
             far = (torch.arange(M, device=dev) // 16).float()[:, None, None] * 10.0
             far = far + 10.0 * torch.rand((M, 1, 1), device=dev) * (far > 0)
             obs[:, 0, :, 0:2] += torch.where(is_lane[:, None, None], torch.zeros_like(los), los * far)
+            if args.sorted:
+                order = torch.from_numpy(np.argsort(np.tile(base["obs_type"], reps)[:M], kind="stable")).to(dev)
+                obs = obs[order].contiguous()
             ring.append(dict(state=torch.from_numpy(np.roll(base["state"], 64 * 331 * (b + 1), axis=0)).float().to(dev),
                              u_ref=torch.from_numpy(np.roll(base["u_ref"], 64 * 331 * (b + 1), axis=0)).float().to(dev),
                              obs=planes_to_tiled(obs)))
             del obs
-        ty = torch.from_numpy(np.tile(base["obs_type"], reps)[:M].copy()).to(dev)
+        ty = np.tile(base["obs_type"], reps)[:M].copy()
+        ty = torch.from_numpy(np.sort(ty, kind="stable") if args.sorted else ty).to(dev)
         u = torch.empty((A, 2), device=dev)
         st = torch.empty((A,), dtype=torch.int32, device=dev)
         slip = torch.zeros((A, 2), device=dev)
         abytes = A * (4 * (4 + 2 + 8 * M + 2) + 4)
-        for name in ("dbm", "kbm", "dum", "sadbm"):
-            f = BatchedCBF(alpha=1.0, R=np.diag([0.5, 0.5]), dynamics=name, streamed_obs=True)
+        for name, lanes in [(n, int(l)) for n in args.models.split(",") for l in args.lanes.split(",")]:
+            f = BatchedCBF(alpha=1.0, R=np.diag([0.5, 0.5]), dynamics=name, streamed_obs=True, lanes_per_qp=lanes)
             kw = dict(slip=slip, dt=0.1) if name == "sadbm" else {}
 
             def walk():
                 for b in ring:
                     f.solve(b["state"], b["u_ref"], b["obs"], ty, u_out=u, status=st, **kw)
-            for _ in range(3):
-                walk()
+            try:
+                for _ in range(3):
+                    walk()
+            except Exception as exc:    # a variant that cannot hold this many rows
+                print("M %4d %-6s lanes %2d: %s" % (M, name, lanes, str(exc)[:60]), flush=True)
+                continue
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
@@ -76,8 +87,8 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 1e3 / (2 * n)
-            print("M %4d %-6s %9.2f us per launch  %.3f of 8 TB/s  infeasible %.2f" %
-                  (M, name, us, abytes / (us * 1e-6) / 8e12, float((st == 1).float().mean())), flush=True)
+            print("M %4d %-6s lanes %2d %9.2f us per launch  %.3f of 8 TB/s  infeasible %.2f" %
+                  (M, name, lanes, us, abytes / (us * 1e-6) / 8e12, float((st == 1).float().mean())), flush=True)
         del ring
         torch.cuda.empty_cache()
 
