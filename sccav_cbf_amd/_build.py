@@ -20,6 +20,12 @@ HIPCC_FLAGS = [
 ]
 
 
+# parts of the one source file (sccbf.hip says which entry points each holds) and their extra flags:
+# the fp64 rollout is compiled without machine-level loop-invariant hoisting, which would keep the
+# double-precision constants of the library transcendentals in registers across its tick loop
+PARTS = [("F32", []), ("F64", []), ("ROLLOUT_F64", ["-mllvm", "-disable-machine-licm"])]
+
+
 def needs_build():
     if not os.path.exists(LIB):
         return True
@@ -34,12 +40,12 @@ def build_library(force=False, verbose=False):
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     os.makedirs(LIB_DIR, exist_ok=True)
-    # the one source file, once per precision, side by side; then one link
+    # the one source file in three parts, side by side; then one link
     cflags = [f for f in HIPCC_FLAGS if f != "-shared"] + ["-I" + os.path.join(_ROOT, "include"), "-c"]
     objs, procs = [], []
-    for tag in ("F32", "F64"):
+    for tag, extra in PARTS:
         obj = os.path.join(LIB_DIR, "sccbf_%s.o" % tag.lower())
-        cmd = [hipcc] + cflags + ["-DSCCBF_ONLY_" + tag, "-o", obj, SRC]
+        cmd = [hipcc] + cflags + ["-DSCCBF_ONLY_" + tag] + extra + ["-o", obj, SRC]
         if verbose:
             print(" ".join(cmd))
         objs.append(obj)

@@ -31,6 +31,29 @@
 #include "sccbf_ext.hip.h"
 #include "sccbf_ingest.hip.h"
 
+// The library is built from this one source in three parts that compile side by side (_build.py):
+// the fp32 entry points, the fp64 ones, and sccbf_rollout_f64 on its own, because that part is compiled
+// without the machine-level hoisting of loop invariants: with it, the 50 double-precision constants of the
+// library tan / atan / atan2 / sincos are parked in registers across the tick loop, 358 registers per lane
+// and one wavefront per SIMD; without it 256 and two, with nothing spilled.  No macro: everything.
+#if defined(SCCBF_ONLY_F32)
+#define SCCBF_HAS_F32 1
+#define SCCBF_HAS_F64 0
+#define SCCBF_HAS_ROLLOUT_F64 0
+#elif defined(SCCBF_ONLY_F64)
+#define SCCBF_HAS_F32 0
+#define SCCBF_HAS_F64 1
+#define SCCBF_HAS_ROLLOUT_F64 0
+#elif defined(SCCBF_ONLY_ROLLOUT_F64)
+#define SCCBF_HAS_F32 0
+#define SCCBF_HAS_F64 0
+#define SCCBF_HAS_ROLLOUT_F64 1
+#else
+#define SCCBF_HAS_F32 1
+#define SCCBF_HAS_F64 1
+#define SCCBF_HAS_ROLLOUT_F64 1
+#endif
+
 namespace {
 
 // ------------------------------------------------------------------- host side
@@ -576,7 +599,7 @@ int lane_fit_impl(int64_t A, int32_t K, int32_t degree, const T* px, const T* py
 
 extern "C" {
 
-#ifndef SCCBF_ONLY_F64
+#if SCCBF_HAS_F32
 int sccbf_ingest_bbox_f32(int64_t A, int32_t M, const float* bbox, const uint8_t* kind, double buffer,
                           uint32_t flags, float* obs, void* stream)
 {
@@ -584,7 +607,7 @@ int sccbf_ingest_bbox_f32(int64_t A, int32_t M, const float* bbox, const uint8_t
 }
 #endif
 
-#ifndef SCCBF_ONLY_F32
+#if SCCBF_HAS_F64
 int sccbf_ingest_bbox_f64(int64_t A, int32_t M, const double* bbox, const uint8_t* kind, double buffer,
                           uint32_t flags, double* obs, void* stream)
 {
@@ -592,21 +615,21 @@ int sccbf_ingest_bbox_f64(int64_t A, int32_t M, const double* bbox, const uint8_
 }
 #endif
 
-#ifndef SCCBF_ONLY_F64
+#if SCCBF_HAS_F32
 int sccbf_prepare_obs_f32(int64_t A, int32_t M, float* obs, uint8_t* obs_type, uint32_t flags, void* stream)
 {
     return prepare_impl<float>(A, M, obs, obs_type, flags, stream);
 }
 #endif
 
-#ifndef SCCBF_ONLY_F32
+#if SCCBF_HAS_F64
 int sccbf_prepare_obs_f64(int64_t A, int32_t M, double* obs, uint8_t* obs_type, uint32_t flags, void* stream)
 {
     return prepare_impl<double>(A, M, obs, obs_type, flags, stream);
 }
 #endif
 
-#ifndef SCCBF_ONLY_F64
+#if SCCBF_HAS_F32
 int sccbf_lane_fit_f32(int64_t A, int32_t K, int32_t degree, const float* px, const float* py,
                        const float* sigma, double buffer, int32_t m, int32_t M, uint32_t flags, float* obs,
                        void* stream)
@@ -615,7 +638,7 @@ int sccbf_lane_fit_f32(int64_t A, int32_t K, int32_t degree, const float* px, co
 }
 #endif
 
-#ifndef SCCBF_ONLY_F32
+#if SCCBF_HAS_F64
 int sccbf_lane_fit_f64(int64_t A, int32_t K, int32_t degree, const double* px, const double* py,
                        const double* sigma, double buffer, int32_t m, int32_t M, uint32_t flags, double* obs,
                        void* stream)
@@ -624,7 +647,7 @@ int sccbf_lane_fit_f64(int64_t A, int32_t K, int32_t degree, const double* px, c
 }
 #endif
 
-#ifndef SCCBF_ONLY_F64
+#if SCCBF_HAS_F32
 int sccbf_solve_step_f32(const sccbf_params* p, double max_steer, double dt, int64_t A, int32_t M, float* state,
                          const float* u_ref, const float* obs, const uint8_t* obs_type, float* u_out,
                          int32_t* status, float* beta_out, void* stream)
@@ -633,7 +656,7 @@ int sccbf_solve_step_f32(const sccbf_params* p, double max_steer, double dt, int
 }
 #endif
 
-#ifndef SCCBF_ONLY_F32
+#if SCCBF_HAS_F64
 int sccbf_solve_step_f64(const sccbf_params* p, double max_steer, double dt, int64_t A, int32_t M, double* state,
                          const double* u_ref, const double* obs, const uint8_t* obs_type, double* u_out,
                          int32_t* status, double* beta_out, void* stream)
@@ -642,11 +665,11 @@ int sccbf_solve_step_f64(const sccbf_params* p, double max_steer, double dt, int
 }
 #endif
 
-#ifndef SCCBF_ONLY_F64
+#if SCCBF_HAS_F32
 int sccbf_version(void) { return SCCBF_VERSION; }
 #endif
 
-#ifndef SCCBF_ONLY_F64
+#if SCCBF_HAS_F32
 const char* sccbf_strerror(int code)
 {
     switch (code) {
@@ -662,7 +685,7 @@ const char* sccbf_strerror(int code)
 }
 #endif
 
-#ifndef SCCBF_ONLY_F64
+#if SCCBF_HAS_F32
 void sccbf_default_params(sccbf_params* p)
 {
     if (!p) return;
@@ -679,7 +702,7 @@ void sccbf_default_params(sccbf_params* p)
 }
 #endif
 
-#ifndef SCCBF_ONLY_F64
+#if SCCBF_HAS_F32
 int sccbf_solve_f32(const sccbf_params* p, int64_t A, int32_t M, const float* state,
                     const float* u_ref, const float* obs, const uint8_t* obs_type, float* u_out,
                     int32_t* status, float* rows_out, void* stream)
@@ -688,7 +711,7 @@ int sccbf_solve_f32(const sccbf_params* p, int64_t A, int32_t M, const float* st
 }
 #endif
 
-#ifndef SCCBF_ONLY_F32
+#if SCCBF_HAS_F64
 int sccbf_solve_f64(const sccbf_params* p, int64_t A, int32_t M, const double* state,
                     const double* u_ref, const double* obs, const uint8_t* obs_type, double* u_out,
                     int32_t* status, double* rows_out, void* stream)
@@ -697,7 +720,7 @@ int sccbf_solve_f64(const sccbf_params* p, int64_t A, int32_t M, const double* s
 }
 #endif
 
-#ifndef SCCBF_ONLY_F64
+#if SCCBF_HAS_F32
 int sccbf_solve_sa_f32(const sccbf_params* p, double dt, int64_t A, int32_t M, const float* state,
                        float* slip, const float* u_ref, const float* obs, const uint8_t* obs_type,
                        float* u_out, int32_t* status, float* rows_out, void* stream)
@@ -706,7 +729,7 @@ int sccbf_solve_sa_f32(const sccbf_params* p, double dt, int64_t A, int32_t M, c
 }
 #endif
 
-#ifndef SCCBF_ONLY_F32
+#if SCCBF_HAS_F64
 int sccbf_solve_sa_f64(const sccbf_params* p, double dt, int64_t A, int32_t M, const double* state,
                        double* slip, const double* u_ref, const double* obs, const uint8_t* obs_type,
                        double* u_out, int32_t* status, double* rows_out, void* stream)
@@ -715,7 +738,7 @@ int sccbf_solve_sa_f64(const sccbf_params* p, double dt, int64_t A, int32_t M, c
 }
 #endif
 
-#ifndef SCCBF_ONLY_F64
+#if SCCBF_HAS_F32
 int sccbf_qp_f32(const sccbf_params* p, int64_t A, int32_t M, const float* rows, const float* u_nom,
                  float* u_out, int32_t* status, void* stream)
 {
@@ -723,7 +746,7 @@ int sccbf_qp_f32(const sccbf_params* p, int64_t A, int32_t M, const float* rows,
 }
 #endif
 
-#ifndef SCCBF_ONLY_F32
+#if SCCBF_HAS_F64
 int sccbf_qp_f64(const sccbf_params* p, int64_t A, int32_t M, const double* rows,
                  const double* u_nom, double* u_out, int32_t* status, void* stream)
 {
@@ -731,7 +754,7 @@ int sccbf_qp_f64(const sccbf_params* p, int64_t A, int32_t M, const double* rows
 }
 #endif
 
-#ifndef SCCBF_ONLY_F64
+#if SCCBF_HAS_F32
 int sccbf_partials_f32(const sccbf_params* p, int64_t A, int32_t M, const float* state,
                        const float* obs, const uint8_t* obs_type, float* out, void* stream)
 {
@@ -739,7 +762,7 @@ int sccbf_partials_f32(const sccbf_params* p, int64_t A, int32_t M, const float*
 }
 #endif
 
-#ifndef SCCBF_ONLY_F32
+#if SCCBF_HAS_F64
 int sccbf_partials_f64(const sccbf_params* p, int64_t A, int32_t M, const double* state,
                        const double* obs, const uint8_t* obs_type, double* out, void* stream)
 {
@@ -747,7 +770,7 @@ int sccbf_partials_f64(const sccbf_params* p, int64_t A, int32_t M, const double
 }
 #endif
 
-#ifndef SCCBF_ONLY_F64
+#if SCCBF_HAS_F32
 void sccbf_default_nominal_params(sccbf_nominal_params* p)
 {
     if (!p) return;
@@ -764,7 +787,7 @@ void sccbf_default_nominal_params(sccbf_nominal_params* p)
 }
 #endif
 
-#ifndef SCCBF_ONLY_F64
+#if SCCBF_HAS_F32
 int sccbf_nominal_f32(const sccbf_nominal_params* p, int64_t A, int32_t N, const float* state,
                       const float* traj, int32_t* target_idx, float* pid_state, float* u_ref, void* stream)
 {
@@ -772,7 +795,7 @@ int sccbf_nominal_f32(const sccbf_nominal_params* p, int64_t A, int32_t N, const
 }
 #endif
 
-#ifndef SCCBF_ONLY_F32
+#if SCCBF_HAS_F64
 int sccbf_nominal_f64(const sccbf_nominal_params* p, int64_t A, int32_t N, const double* state,
                       const double* traj, int32_t* target_idx, double* pid_state, double* u_ref, void* stream)
 {
@@ -780,7 +803,7 @@ int sccbf_nominal_f64(const sccbf_nominal_params* p, int64_t A, int32_t N, const
 }
 #endif
 
-#ifndef SCCBF_ONLY_F64
+#if SCCBF_HAS_F32
 int sccbf_vehicle_step_f32(int64_t A, float* state, const float* u, double lr, double lf, double max_steer,
                            double dt, float* beta_out, void* stream)
 {
@@ -788,7 +811,7 @@ int sccbf_vehicle_step_f32(int64_t A, float* state, const float* u, double lr, d
 }
 #endif
 
-#ifndef SCCBF_ONLY_F32
+#if SCCBF_HAS_F64
 int sccbf_vehicle_step_f64(int64_t A, double* state, const double* u, double lr, double lf, double max_steer,
                            double dt, double* beta_out, void* stream)
 {
@@ -796,7 +819,7 @@ int sccbf_vehicle_step_f64(int64_t A, double* state, const double* u, double lr,
 }
 #endif
 
-#ifndef SCCBF_ONLY_F64
+#if SCCBF_HAS_F32
 void sccbf_default_rollout_params(sccbf_rollout_params* p)
 {
     if (!p) return;
@@ -809,7 +832,7 @@ void sccbf_default_rollout_params(sccbf_rollout_params* p)
 }
 #endif
 
-#ifndef SCCBF_ONLY_F64
+#if SCCBF_HAS_F32
 int sccbf_rollout_f32(const sccbf_params* p, const sccbf_nominal_params* np, const sccbf_rollout_params* rp,
                       int64_t A, int32_t M, int32_t N, float* state, const float* traj, int32_t* target_idx,
                       float* pid_state, float* slip, const float* obs, const uint8_t* obs_type, float* h_min,
@@ -820,7 +843,7 @@ int sccbf_rollout_f32(const sccbf_params* p, const sccbf_nominal_params* np, con
 }
 #endif
 
-#ifndef SCCBF_ONLY_F64
+#if SCCBF_HAS_F32
 int sccbf_vehicle_step_kin_f32(int64_t A, float* state, const float* u, int32_t mode, double L, double max_steer,
                                double dt, void* stream)
 {
@@ -828,7 +851,7 @@ int sccbf_vehicle_step_kin_f32(int64_t A, float* state, const float* u, int32_t 
 }
 #endif
 
-#ifndef SCCBF_ONLY_F32
+#if SCCBF_HAS_F64
 int sccbf_vehicle_step_kin_f64(int64_t A, double* state, const double* u, int32_t mode, double L, double max_steer,
                                double dt, void* stream)
 {
@@ -836,7 +859,7 @@ int sccbf_vehicle_step_kin_f64(int64_t A, double* state, const double* u, int32_
 }
 #endif
 
-#ifndef SCCBF_ONLY_F32
+#if SCCBF_HAS_ROLLOUT_F64
 int sccbf_rollout_f64(const sccbf_params* p, const sccbf_nominal_params* np, const sccbf_rollout_params* rp,
                       int64_t A, int32_t M, int32_t N, double* state, const double* traj, int32_t* target_idx,
                       double* pid_state, double* slip, const double* obs, const uint8_t* obs_type, double* h_min,

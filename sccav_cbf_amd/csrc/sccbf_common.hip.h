@@ -22,7 +22,7 @@ constexpr int kTile = SCCBF_TILE;
 #define SCCBF_ROLLOUT_WAVES 4  // wavefronts per SIMD the fp32 rollout (up to 16 slots per agent) is held to
 #endif
 #ifndef SCCBF_ROLLOUT_WAVES_F64
-#define SCCBF_ROLLOUT_WAVES_F64 1  // and the fp64 one: 256 registers per lane
+#define SCCBF_ROLLOUT_WAVES_F64 2  // and the fp64 one: 256 registers per lane (built without machine LICM, see sccbf.hip)
 #endif
 #ifndef SCCBF_CAP_PER_ROW
 #define SCCBF_CAP_PER_ROW 8
