@@ -34,18 +34,21 @@ def needs_build():
     return any(os.path.getmtime(f) > t for f in deps)
 
 
-def build_library(force=False, verbose=False):
-    """Compile the shared library in-tree; returns its path."""
-    if not force and not needs_build():
+def build_library(force=False, verbose=False, out=None, extra_flags=()):
+    """Compile the shared library in-tree; returns its path.  `out` / `extra_flags`: a variant build beside
+    the library (for A/B measurements: load it with SCCBF_LIBRARY=<path>), always compiled."""
+    if out is None and not force and not needs_build():
         return LIB
+    variant = out is not None
+    out = out or LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     os.makedirs(LIB_DIR, exist_ok=True)
     # the one source file in three parts, side by side; then one link
     cflags = [f for f in HIPCC_FLAGS if f != "-shared"] + ["-I" + os.path.join(_ROOT, "include"), "-c"]
     objs, procs = [], []
     for tag, extra in PARTS:
-        obj = os.path.join(LIB_DIR, "sccbf_%s.o" % tag.lower())
-        cmd = [hipcc] + cflags + ["-DSCCBF_ONLY_" + tag] + extra + ["-o", obj, SRC]
+        obj = os.path.join(LIB_DIR, "sccbf_%s%s.o" % (tag.lower(), "_variant" if variant else ""))
+        cmd = [hipcc] + cflags + ["-DSCCBF_ONLY_" + tag] + extra + list(extra_flags) + ["-o", obj, SRC]
         if verbose:
             print(" ".join(cmd))
         objs.append(obj)
@@ -53,7 +56,7 @@ def build_library(force=False, verbose=False):
     logs = [p.communicate()[0] for p in procs]
     if any(p.returncode != 0 for p in procs):
         raise RuntimeError("hipcc failed:\n" + "\n".join(logs))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs
     if verbose:
         print(" ".join(cmd))
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
@@ -61,7 +64,7 @@ def build_library(force=False, verbose=False):
         raise RuntimeError("hipcc link failed:\n" + res.stdout)
     for obj in objs:
         os.remove(obj)
-    return LIB
+    return out
 
 
 if __name__ == "__main__":

@@ -57,3 +57,23 @@ def test_other_variants_have_no_scratch(asm):
                  "_ZN12_GLOBAL__N_17k_groupIdLi4ELi4ELb0ELb0EEEv", "_ZN12_GLOBAL__N_19k_nominalIfEEv"):
         _, meta = _kernel(asm, name)
         assert _meta(meta, "private_segment_fixed_size") == 0, name
+
+
+def test_fp64_rollout_fits_two_waves_without_scratch(tmp_path):
+    # the fp64 rollout as its part of the library is compiled (no machine-level hoisting of loop invariants):
+    # k_rollout<double, 4, false, 4> within 256 registers per lane, nothing spilled
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not available")
+    src = tmp_path / "rollout_f64.hip"
+    src.write_text('#include "sccbf_loop.hip.h"\nnamespace {\n'
+                   'template __global__ void k_rollout<double, 4, false, 4>(const RArgs<double>);\n}\n')
+    extra = dict(_build.PARTS)["ROLLOUT_F64"]
+    flags = [f for f in _build.HIPCC_FLAGS if f not in ("-shared", "-fPIC")] + extra
+    out = tmp_path / "rollout_f64.s"
+    cmd = [HIPCC] + flags + ["--cuda-device-only", "-S", "-I" + os.path.dirname(_build.HDR), "-I" + _build.CSRC,
+                             "-o", str(out), str(src)]
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert res.returncode == 0, res.stdout[-2000:]
+    _, meta = _kernel(out.read_text(), "_ZN12_GLOBAL__N_19k_rolloutIdLi4ELb0ELi4EEE")
+    assert _meta(meta, "private_segment_fixed_size") == 0
+    assert _meta(meta, "next_free_vgpr") <= 256
