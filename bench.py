@@ -388,7 +388,8 @@ def worker(args):
     else:
         stream = torch.cuda.Stream(device)
         with torch.cuda.stream(stream):
-            glen = max(RING, 10)   # launches per captured walk
+            # launches per captured walk: whole walks over the ring, one replay for a short timed region
+            glen = RING * max(1, -(-min(max(args.steps, 10), 100) // RING))
             for i in range(glen):
                 step(i)
             torch.cuda.synchronize()
@@ -482,7 +483,7 @@ def worker(args):
                        "obs_layout": layout_name,
                        "obs_slots": "prepared (kinds 4, 5: 1/a^2, 1/b^2, cos, sin and the cone's obstacle velocity "
                                     "stored in the slot)" if args.slots == "prepared" else "as written (kinds 0, 1)",
-                       "launch": "eager" if graph is None else "hipGraph of %d launches" % max(RING, 10),
+                       "launch": "eager" if graph is None else "hipGraph of %d launches" % glen,
                        "clock_ramp_steps_before_warmup": ramp_steps},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": _profile_json("traffic.json"),
