@@ -73,7 +73,7 @@ extern "C" {
                            (a drives v, omega drives yaw), drift [v cos, v sin, 0, 0]; as written the
                            drift is declared 5x1 with four entries (243-245) and the class does not run:
                            here with the 4x1 drift.  No steering transform (247-298 apply none).
-                           lanes_per_qp 0, 4 (M <= 64), 16, 32 or 64 */
+                           lanes_per_qp 0, 4 (M <= 64), 8 (M <= 128), 16, 32 or 64 */
 #define SCCBF_DYN_SADBM 3 /* SADBM_CBF_2DS, reference cbf/cbf.py:301-437: slip angle beta is a fifth
                              state, u = [a, d(beta)/dt].  Only through sccbf_solve_sa_* */
 
@@ -181,7 +181,7 @@ int sccbf_solve_f64(const sccbf_params* p, int64_t A, int32_t M,
  * SCCBF_STATUS_NONFINITE: u_out = u_ref and the slip state is left as it was.
  * Cone slots read their own beta o[5] unless SCCBF_FLAG_CONE_BETA_STATE is set.
  * p->dynamics is ignored; SCCBF_FLAG_SLIP_IO is not allowed; M >= 1 (an empty list raises
- * in the reference, 375-378); rows_out as in sccbf_solve_*; lanes_per_qp 0, 4 (M <= 64), 16, 32 or 64.
+ * in the reference, 375-378); rows_out as in sccbf_solve_*; lanes_per_qp 0, 4 (M <= 64), 8 (M <= 128), 16, 32 or 64.
  */
 int sccbf_solve_sa_f32(const sccbf_params* p, double dt, int64_t A, int32_t M,
                        const float* state, float* slip, const float* u_ref,

@@ -235,7 +235,7 @@ int dispatch(const sccbf_params* sp, KArgs<T>& k, void* stream)
     }
 }
 
-// unicycle-input and steer-rate models: 4 lanes per QP for large batches, else 16
+// unicycle-input and steer-rate models: 4, 8 or 16 lanes per QP with the rows in registers
 template <typename T, int G>
 int launch_ext_rpl(const KArgs<T>& k, const XArgs<T>& x, hipStream_t s)
 {
@@ -277,8 +277,13 @@ int dispatch_ext(const sccbf_params* sp, const KArgs<T>& k, const XArgs<T>& x, v
 {
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     int lanes = sp->lanes_per_qp;
-    if (lanes == 0) lanes = k.M > 128 ? wave_lanes<T>(k.M) : ((k.A >= (1 << 13) && k.M <= 64) ? 4 : 16);
+    if (lanes == 0) {  // as for the bicycle models (auto_lanes)
+        if (k.M > 128) lanes = wave_lanes<T>(k.M);
+        else if (k.A >= (1 << 13)) lanes = k.M <= 16 ? 4 : 8;
+        else lanes = 16;
+    }
     if (lanes == 4 && k.M <= 64) return launch_ext_rpl<T, 4>(k, x, s);
+    if (lanes == 8 && k.M <= 128) return launch_ext_rpl<T, 8>(k, x, s);
     if (lanes == 16) return k.M <= 256 ? launch_ext_rpl<T, 16>(k, x, s) : launch_wave_ext<T, 16>(k, x, s);
     if (lanes == 32) return launch_wave_ext<T, 32>(k, x, s);
     if (lanes == 64) return launch_wave_ext<T, 64>(k, x, s);

@@ -78,8 +78,8 @@ def main():
         lanes = int(rng.choice([0, 1, 2, 4, 8, 16, 32, 64]))
         if lanes not in (0, 16, 32, 64) and M > 16 * lanes:
             lanes = 0
-        if dyn in ("dum", "sadbm"):     # these models run with 4 lanes per QP (up to 64 rows), 16, 32 or 64
-            lanes = lanes if lanes in (0, 16, 32, 64) or (lanes == 4 and M <= 64) else 0
+        if dyn in ("dum", "sadbm"):     # these models run with 4 lanes per QP (up to 64 rows), 8 (128), 16, 32 or 64
+            lanes = lanes if lanes in (0, 16, 32, 64) or (lanes == 4 and M <= 64) or (lanes == 8 and M <= 128) else 0
         sa_dt = float(rng.choice([0.02, 0.1]))
         sa_slip = np.stack([rng.uniform(-0.3, 0.3, A), rng.uniform(-0.3, 0.3, A)], axis=1)
         cone_beta = bool(rng.integers(0, 2))

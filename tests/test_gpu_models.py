@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
-@pytest.mark.parametrize("lanes", [0, 4, 16])
+@pytest.mark.parametrize("lanes", [0, 4, 8, 16])
 @pytest.mark.parametrize("name", ["mixed16", "lanes2_cones6"])
 def test_dum_matches_oracle(oracle, name, dtype, lanes):
     w = scenarios.config4(A=4096, nominal="uniform") if name == "mixed16" else scenarios.lanes_and_cones(A=4096)
@@ -34,7 +34,7 @@ def test_dum_matches_oracle(oracle, name, dtype, lanes):
 
 
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
-@pytest.mark.parametrize("lanes,cone_beta_state", [(0, True), (4, False), (16, True)])
+@pytest.mark.parametrize("lanes,cone_beta_state", [(0, True), (4, False), (8, False), (16, True)])
 def test_sadbm_matches_oracle_over_ticks(oracle, dtype, lanes, cone_beta_state):
     """Four ticks of SADBM_CBF_2DS.solve_cbf (cbf/cbf.py:349-437) for 4096 agents: each tick starts
     from the oracle's slip state, the agents move by the oracle's vehicle step in between."""

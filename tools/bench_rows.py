@@ -33,7 +33,8 @@ def main():
     for M in [int(m) for m in args.rows.split(",")]:
         reps = -(-M // 16)
         ring = []
-        for b in range(2):
+        nring = max(2, -(-600_000_000 // (A * (32 * M + 36))))   # distinct batches: more than twice the Infinity Cache
+        for b in range(nring):
             sh = 64 * 331 * (b + 1)
             obs = torch.from_numpy(np.roll(base["obs"], sh, axis=2)).float().to(dev)
             obs = obs.repeat(reps, 1, 1, 1)[:M].contiguous()
@@ -63,7 +64,7 @@ def main():
             f = BatchedCBF(alpha=1.0, R=np.diag([0.5, 0.5]), dynamics=name, streamed_obs=True, lanes_per_qp=lanes)
             kw = dict(slip=slip, dt=0.1) if name == "sadbm" else {}
 
-            inner = 5   # launches per captured walk: 10, so that a replay's own start is a small share
+            inner = max(1, 10 // nring)   # about 10 launches per captured walk: a replay's own start is a small share
 
             def walk():
                 for b in ring * inner:
@@ -88,7 +89,7 @@ def main():
                 g.replay()
             e1.record()
             torch.cuda.synchronize()
-            us = e0.elapsed_time(e1) * 1e3 / (2 * inner * n)
+            us = e0.elapsed_time(e1) * 1e3 / (nring * inner * n)
             print("M %4d %-6s lanes %2d %9.2f us per launch  %.3f of 8 TB/s  infeasible %.2f" %
                   (M, name, lanes, us, abytes / (us * 1e-6) / 8e12, float((st == 1).float().mean())), flush=True)
         del ring

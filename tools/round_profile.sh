@@ -5,6 +5,7 @@ set -e
 timeout -k 10 300 python -u -m pytest tests -m gpu -x -q --timeout 120 --timeout-method thread > gpurun_out/r2_gpu_tests.log 2>&1
 timeout -k 10 400 python -u bench.py > gpurun_out/r2_bench.json 2> gpurun_out/r2_bench.err
 bash tools/prof_kernel.sh r2_stats > gpurun_out/r2_stats.txt 2>&1
+bash tools/prof_kernel.sh r2_stats_eager --no-graph --steps 500 --warmup 50 > gpurun_out/r2_stats_eager.txt 2>&1
 bash tools/prof_pmc.sh r2_pmc_fsize "FETCH_SIZE" > gpurun_out/r2_pmc_fsize.txt 2>&1
 bash tools/prof_pmc.sh r2_pmc_write "WRITE_SIZE TCC_EA0_WRREQ_sum" > gpurun_out/r2_pmc_write.txt 2>&1
 bash tools/prof_pmc.sh r2_pmc_sq "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU" > gpurun_out/r2_pmc_sq.txt 2>&1
