@@ -312,6 +312,7 @@ def worker(args):
         return 2
     stub = args.cpu_stub
     dist = None
+    _saved_stdout = None
     if stub:
         device = torch.device("cpu")
     else:
@@ -321,9 +322,17 @@ def worker(args):
             return 2
         device = torch.device("cuda", local)
         torch.cuda.set_device(device)
-    if world > 1:
+    # started as a rank (by the launcher below or by torch.distributed.run): the process group is set up even
+    # for a single rank, so that the collective path of an N = 1 run under a launcher is the N > 1 path
+    if world > 1 or ("RANK" in os.environ and "WORLD_SIZE" in os.environ):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        # the collective library prints a version banner on stdout when it starts: until the JSON line is
+        # due, whatever is written to file descriptor 1 goes to stderr
+        sys.stdout.flush()
+        _saved_stdout = os.dup(1)
+        os.dup2(2, 1)
         if stub:
             dist.init_process_group("gloo")
         else:
@@ -498,7 +507,7 @@ def worker(args):
             out["data"] = "none (cpu stub: launcher rehearsal, nothing measured)"
             out["stub"] = True
             out["roofline"] = None
-        if world > 1:
+        if dist is not None:
             out["rccl_ranks" if not stub else "gloo_ranks"] = coll_ranks
             out["ms_per_step_by_rank"] = rank_ms
             out["gather_ms_per_step"] = gather_ms   # not part of value / ms_per_step
@@ -519,6 +528,9 @@ def worker(args):
                 out["fp64"] = {"error": repr(e)}
         if world == 1 and not stub and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline()
+        if _saved_stdout is not None:
+            sys.stdout.flush()
+            os.dup2(_saved_stdout, 1)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
