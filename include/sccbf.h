@@ -45,6 +45,16 @@
  * filter does no sine, cosine or reciprocal per slot and tick; same 8 scalars, same rows
  *   SCCBF_OBS_ELLIPSE_PREP  cx, cy, 1/a^2, 1/b^2, cos(theta_o), sin(theta_o), vx, vy
  *   SCCBF_OBS_CONE_PREP     cx, cy, v_o cos(theta_o + beta), v_o sin(theta_o + beta), a, beta, -, -
+ * Box kinds: the slot is the obstacle's bounding box as perception delivers it (BoundingBox, reference
+ * cbf/obstacles.py:59-64) plus the safety buffer, and the filter makes the obstacle from it on the fly,
+ * as ObstacleList2D.update_by_bounding_box does on every tick (833-858): no ingestion pass in between
+ *   SCCBF_OBS_ELLIPSE_BOX   loc x, loc y, extent x, extent y, yaw, speed, buffer, -
+ *                           Ellipse2D.from_bounding_box (320-331): a = extent x + buffer,
+ *                           b = extent y + buffer, theta_o = yaw, at rest
+ *   SCCBF_OBS_CONE_BOX      the same record; CollisionCone2D.from_bounding_box (534-543):
+ *                           a = hypot(extent x, extent y) + buffer, theta_o = 0, v_o = speed
+ * Same answers as sccbf_ingest_bbox_* followed by the filter (ellipse rows bit for bit, cone rows to the
+ * last few bits).
  */
 #ifndef SCCBF_H_
 #define SCCBF_H_
@@ -55,7 +65,7 @@
 extern "C" {
 #endif
 
-#define SCCBF_VERSION 200 /* 0.2.0 */
+#define SCCBF_VERSION 201 /* 0.2.1 */
 
 /* obstacle kinds: 0..2 follow Obstacle2DTypes, reference cbf/obstacles.py:51-57 */
 #define SCCBF_OBS_ELLIPSE 0
@@ -64,6 +74,8 @@ extern "C" {
 #define SCCBF_OBS_RADIAL 3 /* test_scripts/radial_dynamic_obstacles.py:391-411 */
 #define SCCBF_OBS_ELLIPSE_PREP 4 /* Ellipse2D, reference cbf/obstacles.py:183-236, 310-317, constants evaluated */
 #define SCCBF_OBS_CONE_PREP 5    /* CollisionCone2D, cbf/obstacles.py:401-502, obstacle velocity resolved */
+#define SCCBF_OBS_ELLIPSE_BOX 6  /* Ellipse2D.from_bounding_box, cbf/obstacles.py:320-331, made from the box per tick */
+#define SCCBF_OBS_CONE_BOX 7     /* CollisionCone2D.from_bounding_box, cbf/obstacles.py:534-543, likewise */
 #define SCCBF_OBS_EMPTY 255
 
 /* vehicle model */

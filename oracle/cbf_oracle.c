@@ -35,6 +35,8 @@
 #define ORC_OBS_RADIAL 3
 #define ORC_OBS_ELLIPSE_PREP 4
 #define ORC_OBS_CONE_PREP 5
+#define ORC_OBS_ELLIPSE_BOX 6
+#define ORC_OBS_CONE_BOX 7
 #define ORC_OBS_EMPTY 255
 
 #define ORC_DYN_DBM 0
@@ -216,9 +218,29 @@ static void orc_lane(const double s[4], const double o[8], double eps, orc_parti
     r->ht = 0.0;
 }
 
-/* returns 0 for an empty slot (no row), 1 otherwise */
-int orc_barrier(int type, const double s[4], const double o[8], double zero_tol, orc_partials* r)
+/* Box kinds: the slot holds a bounding box (reference cbf/obstacles.py:59-64: location x, y, extent x, y, yaw,
+ * speed) and the buffer; Ellipse2D.from_bounding_box (320-331: a = extent x + buffer, b = extent y + buffer,
+ * theta = yaw, at rest) or CollisionCone2D.from_bounding_box (534-543: a = hypot(extent) + buffer,
+ * s_obs = [x, y, 0, speed]) makes the obstacle.  In place: type and slot become the as-written kind. */
+static void orc_unbox(int* type, double o[8])
 {
+    if (*type == ORC_OBS_ELLIPSE_BOX) {
+        const double q[8] = {o[0], o[1], o[2] + o[6], o[3] + o[6], o[4], 0.0, 0.0, 0.0};
+        memcpy(o, q, sizeof(q));
+        *type = ORC_OBS_ELLIPSE;
+    } else if (*type == ORC_OBS_CONE_BOX) {
+        const double q[8] = {o[0], o[1], 0.0, o[5], hypot(o[2], o[3]) + o[6], 0.0, 0.0, 0.0};
+        memcpy(o, q, sizeof(q));
+        *type = ORC_OBS_CONE;
+    }
+}
+
+/* returns 0 for an empty slot (no row), 1 otherwise */
+int orc_barrier(int type, const double s[4], const double o_in[8], double zero_tol, orc_partials* r)
+{
+    double o[8];
+    memcpy(o, o_in, sizeof(o));
+    orc_unbox(&type, o);
     switch (type) {
     case ORC_OBS_ELLIPSE: orc_ellipse(s, o, r); return 1;
     case ORC_OBS_CONE: orc_cone(s, o, zero_tol, r); return 1;
@@ -555,6 +577,7 @@ int orc_solve_sa_batch(const orc_params* p, double dt, int64_t A, int32_t M, con
                     o[4 * h + c] = shared ? obs[((size_t)m * 2 + h) * 4 + c]
                                           : obs[(((size_t)m * 2 + h) * A + a) * 4 + c];
             int type = type_pa ? obs_type[(size_t)m * A + a] : obs_type[m];
+            orc_unbox(&type, o);
             if (type == ORC_OBS_CONE && (p->flags & ORC_FLAG_CONE_BETA_STATE)) o[5] = beta;
             orc_partials d;
             double* row = rows + 3 * m;

@@ -15,6 +15,7 @@ _SO = os.path.join(_HERE, "liboracle.so")
 
 OBS_ELLIPSE, OBS_CONE, OBS_LANE, OBS_RADIAL, OBS_EMPTY = 0, 1, 2, 3, 255
 OBS_ELLIPSE_PREP, OBS_CONE_PREP = 4, 5
+OBS_ELLIPSE_BOX, OBS_CONE_BOX = 6, 7   # the slot is the bounding box itself: x, y, extent x, y | yaw, speed, buffer
 DYN_DBM, DYN_KBM, DYN_DUM, DYN_SADBM = 0, 1, 2, 3
 FLAG_OBS_SHARED, FLAG_TYPE_PER_AGENT, FLAG_SLIP_IO = 1, 2, 4
 FLAG_CONE_BETA_STATE = 16
@@ -296,6 +297,8 @@ def seeker_step(obs, obs_type, ego_xy, dt, k=0.2, v_min=3.0):
         elif kind == OBS_CONE_PREP:
             obs[m, 0, :, 0] += obs[m, 0, :, 2] * dt
             obs[m, 0, :, 1] += obs[m, 0, :, 3] * dt
+        elif kind == OBS_CONE_BOX:       # theta_o = 0: along x at the box's speed (an ellipse box is at rest)
+            obs[m, 0, :, 0] += obs[m, 1, :, 1] * dt
 
 
 def ingest_bbox(bbox, kind, buffer=0.5):

@@ -86,7 +86,7 @@ __device__ inline int lane_rows_(const KArgs<T>& p, long long qp, int m0, int dm
             slot_row_(ty, o, e, p, a0, a1, b, h);
             if (p.rows_out && m < M && live)
                 reinterpret_cast<v4*>(p.rows_out)[(long long)m * p.A + qp] = v4{a0, a1, b, h};
-            if (h_min && ty >= 0 && ty <= SCCBF_OBS_CONE_PREP) *h_min = min_(*h_min, h);  // real slots only
+            if (h_min && ty >= 0 && ty <= SCCBF_OBS_CONE_BOX) *h_min = min_(*h_min, h);  // real slots only
         }
         chk += a0 * T(0) + a1 * T(0) + b * T(0);
         to_wspace_(a0, a1, b, e, p, at0[r], at1[r], bt[r]);
@@ -424,14 +424,11 @@ __global__ __launch_bounds__(kBlock) void k_partials(const KArgs<T> p)
     sincos_(s.z, &sth, &cth);
     const T o[8] = {oa.x, oa.y, oa.z, oa.w, ob.x, ob.y, ob.z, ob.w};
     Partials<T> d;
-    switch (ty) {
-    case SCCBF_OBS_ELLIPSE: ellipse_(s.x, s.y, o, d); break;
-    case SCCBF_OBS_CONE: cone_(s.x, s.y, s.z, s.w, cth, sth, o, p.zero_tol, d); break;
-    case SCCBF_OBS_LANE: lane_(s.x, s.y, o, p.zero_tol, d); break;
-    case SCCBF_OBS_RADIAL: radial_(s.x, s.y, s.w, o, d); break;
-    case SCCBF_OBS_ELLIPSE_PREP: ellipse_prep_(s.x, s.y, o, d); break;
-    case SCCBF_OBS_CONE_PREP: cone_prep_(s.x, s.y, s.z, s.w, cth, sth, o, p.zero_tol, d); break;
-    default: d.h = T(1); d.hx = d.hy = d.hth = d.hv = d.ht = T(0); break;
+    Ego<T> e;
+    e.x = s.x; e.y = s.y; e.th = s.z; e.v = s.w; e.cth = cth; e.sth = sth;
+    if (!slot_partials_(ty, o, e, p, d)) {
+        d.h = T(1);
+        d.hx = d.hy = d.hth = d.hv = d.ht = T(0);
     }
     v4* out = reinterpret_cast<v4*>(p.rows_out);
     out[(long long)m * 2 * p.A + a] = v4{d.h, d.hx, d.hy, d.hth};

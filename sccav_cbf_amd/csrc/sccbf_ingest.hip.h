@@ -45,14 +45,14 @@ __global__ __launch_bounds__(kBlock) void k_ingest(const IArgs<T> p)
         ob = v4{b1.x, T(0), T(0), T(0)};
     } else if (kind == SCCBF_OBS_CONE) {
         oa = v4{b0.x, b0.y, T(0), b1.y};
-        ob = v4{sqrt_(b0.z * b0.z + b0.w * b0.w) + p.buffer, T(0), T(0), T(0)};
+        ob = v4{box_cone_radius_(b0.z, b0.w, p.buffer), T(0), T(0), T(0)};
     } else if (kind == SCCBF_OBS_ELLIPSE_PREP) {  // the same ellipse, constants evaluated (in double)
         const double a = (double)(b0.z + p.buffer), b = (double)(b0.w + p.buffer);
         oa = v4{b0.x, b0.y, (T)(1.0 / (a * a)), (T)(1.0 / (b * b))};
         ob = v4{(T)cos((double)b1.x), (T)sin((double)b1.x), T(0), T(0)};
     } else if (kind == SCCBF_OBS_CONE_PREP) {     // theta_o = 0, beta = 0: the velocity is (speed, 0)
         oa = v4{b0.x, b0.y, b1.y, T(0)};
-        ob = v4{sqrt_(b0.z * b0.z + b0.w * b0.w) + p.buffer, T(0), T(0), T(0)};
+        ob = v4{box_cone_radius_(b0.z, b0.w, p.buffer), T(0), T(0), T(0)};
     }
     const ObsAddr ad = slot_addr_<T>(p.A, p.M, p.flags, a);
     v4* out = reinterpret_cast<v4*>(p.obs);

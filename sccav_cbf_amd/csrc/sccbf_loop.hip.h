@@ -358,7 +358,7 @@ template <typename T> struct RArgs {
 };
 
 // obstacle slots move between ticks (constant velocity): ellipse by (vx, vy), collision cone by
-// v_o along theta_o + beta, radial by (cdot_x, cdot_y); lanes and empty slots stay
+// v_o along theta_o + beta, radial by (cdot_x, cdot_y); lanes, empty slots and ellipse boxes stay
 template <typename T>
 __device__ inline void advance_slot_(int type, typename VT<T>::v4& oa, typename VT<T>::v4& ob, T dt)
 {
@@ -379,6 +379,8 @@ __device__ inline void advance_slot_(int type, typename VT<T>::v4& oa, typename 
     } else if (type == SCCBF_OBS_CONE_PREP) {
         oa.x += oa.z * dt;
         oa.y += oa.w * dt;
+    } else if (type == SCCBF_OBS_CONE_BOX) {  // theta_o = 0: along x at the box's speed; an ellipse box is at rest
+        oa.x += ob.y * dt;
     }
 }
 
@@ -560,7 +562,7 @@ void k_rollout(const RArgs<T> a)
                 const int ty = m < p.M ? L.ty[r] : SCCBF_OBS_EMPTY;
                 T a0, a1, b, h;
                 ext_slot_row_(ty, o, e, p, sadbm, sadbm, sl.x, cthb, sthb, sb, a0, a1, b, h);
-                if (ty >= 0 && ty <= SCCBF_OBS_CONE_PREP) hm = min_(hm, h);
+                if (ty >= 0 && ty <= SCCBF_OBS_CONE_BOX) hm = min_(hm, h);
                 chk += a0 * T(0) + a1 * T(0) + b * T(0);
                 to_wspace_(a0, a1, b, e, p, at0[r], at1[r], bt[r]);
             }

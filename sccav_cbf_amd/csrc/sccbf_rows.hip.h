@@ -112,6 +112,36 @@ __device__ inline void cone_prep_(T x, T y, T th, T v, T cth, T sth, const T o[8
     cone_core_(x - o[0], y - o[1], v * cth, v * sth, o[2], o[3], o[4], c, sn, eps, r);
 }
 
+// Box kinds: o = loc x, loc y, extent x, extent y, yaw, speed, buffer (BoundingBox, reference
+// cbf/obstacles.py:59-64, and the buffer of from_bounding_box) -> the as-written slot of the obstacle that
+// Ellipse2D.from_bounding_box (320-331) / CollisionCone2D.from_bounding_box (534-543) make of it, by the
+// same arithmetic as k_ingest.
+// radius of the cone around a box: both squares rounded, then their sum (no fused multiply-add, whose choice of
+// the fused product could differ from one inlined copy to the next), the root, the buffer
+template <typename T> __device__ inline T box_cone_radius_(T ex, T ey, T buffer)
+{
+#pragma clang fp contract(off)
+    const T s2 = ex * ex + ey * ey;
+    return sqrt_(s2) + buffer;
+}
+
+template <typename T> __device__ inline void box_ellipse_(const T o[8], T q[8])
+{
+    q[0] = o[0]; q[1] = o[1]; q[2] = o[2] + o[6]; q[3] = o[3] + o[6];
+    q[4] = o[4]; q[5] = T(0); q[6] = T(0); q[7] = T(0);
+}
+template <typename T> __device__ inline void box_cone_(const T o[8], T q[8])  // theta_o = 0, beta = 0
+{
+    q[0] = o[0]; q[1] = o[1]; q[2] = T(0); q[3] = o[5];
+    q[4] = box_cone_radius_(o[2], o[3], o[6]); q[5] = T(0); q[6] = T(0); q[7] = T(0);
+}
+// the same cone with its velocity (speed, 0) resolved: the prepared form, no sine / cosine
+template <typename T> __device__ inline void box_cone_prep_(const T o[8], T q[8])
+{
+    q[0] = o[0]; q[1] = o[1]; q[2] = o[5]; q[3] = T(0);
+    q[4] = box_cone_radius_(o[2], o[3], o[6]); q[5] = T(0); q[6] = T(0); q[7] = T(0);
+}
+
 template <typename T> __device__ inline void poly3_(const T c[4], T x, T& f, T& df, T& ddf)
 {
     f = c[0] + x * (c[1] + x * (c[2] + x * c[3]));
@@ -242,6 +272,18 @@ __device__ inline bool slot_partials_(int type, const T o[8], const Ego<T>& e, c
     case SCCBF_OBS_RADIAL: radial_(e.x, e.y, e.v, o, d); return true;
     case SCCBF_OBS_ELLIPSE_PREP: ellipse_prep_(e.x, e.y, o, d); return true;
     case SCCBF_OBS_CONE_PREP: cone_prep_(e.x, e.y, e.th, e.v, e.cth, e.sth, o, p.zero_tol, d); return true;
+    case SCCBF_OBS_ELLIPSE_BOX: {
+        T q[8];
+        box_ellipse_(o, q);
+        ellipse_(e.x, e.y, q, d);
+        return true;
+    }
+    case SCCBF_OBS_CONE_BOX: {
+        T q[8];
+        box_cone_prep_(o, q);
+        cone_prep_(e.x, e.y, e.th, e.v, e.cth, e.sth, q, p.zero_tol, d);
+        return true;
+    }
     default: return false;
     }
 }

@@ -58,6 +58,27 @@ def ingest_bbox(bbox, kind, buffer=0.5, tiled=False, out=None):
     return out
 
 
+def bbox_as_obs(bbox, kind, buffer=0.5):
+    """No ingestion pass at all: the box records themselves become the filter's obstacle slots.  Writes
+    `buffer` into component [m, 1, :, 2] of bbox (M,2,A,4) = location x, y, extent x, y | yaw, speed, -, -
+    IN PLACE and returns (bbox, obs_type) with the ellipse kinds of `kind` (uint8 (M,) or (M,A)) turned into
+    OBS_ELLIPSE_BOX and the cone kinds into OBS_CONE_BOX: the filter then makes
+    Ellipse2D.from_bounding_box / CollisionCone2D.from_bounding_box (reference cbf/obstacles.py:320-331,
+    534-543) of every box on every tick, as ObstacleList2D.update_by_bounding_box does (833-858), with the
+    answers of ingest_bbox(...) followed by the solve.  Other kinds keep their slot as it is."""
+    M, A = bbox.shape[0], bbox.shape[2]
+    _check("bbox", bbox, (M, 2, A, 4), bbox.dtype, bbox.device)
+    ty = kind.clone()
+    ell = (kind == _lib.OBS_ELLIPSE) | (kind == _lib.OBS_ELLIPSE_PREP)
+    cone = (kind == _lib.OBS_CONE) | (kind == _lib.OBS_CONE_PREP)
+    ty[ell] = _lib.OBS_ELLIPSE_BOX
+    ty[cone] = _lib.OBS_CONE_BOX
+    boxed = (ell | cone)
+    boxed = boxed if boxed.dim() == 2 else boxed[:, None].expand(M, A)
+    bbox[:, 1, :, 2] = torch.where(boxed, torch.as_tensor(buffer, dtype=bbox.dtype, device=bbox.device), bbox[:, 1, :, 2])
+    return bbox, ty
+
+
 def lane_fit(px, py, obs, slot, sigma=None, degree=3, buffer=1.5):
     """px, py (K,A): lane points of every agent; sigma (K,A) or None (10 everywhere; a fixed point
     is a point with a small sigma, a point with sigma <= 0 is skipped).  Writes lane slot `slot`

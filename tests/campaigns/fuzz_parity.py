@@ -51,6 +51,16 @@ def random_case(rng, A, M):
     take = (rng.uniform(size=M) < 0.5) & ((kinds == 0) | (kinds == 1))
     obs[take] = wp["obs"][take]
     kinds = np.where(take, wp["obs_type"], kinds).astype(np.uint8)
+    # a fifth of the slots as bounding boxes (kinds 6, 7: x, y, extent x, y | yaw, speed, buffer): the filter makes the
+    # ellipse / cone of from_bounding_box out of them
+    for m in range(M):
+        if kinds[m] != 255 and rng.uniform() < 0.2:
+            rg, br = rng.uniform(8, 60, A), rng.uniform(-np.pi, np.pi, A)
+            box = np.stack([state[:, 0] + rg * np.cos(br), state[:, 1] + rg * np.sin(br), rng.uniform(1.5, 4, A),
+                            rng.uniform(0.7, 2, A), rng.uniform(-3.1, 3.1, A), rng.uniform(0, 8, A),
+                            np.full(A, rng.uniform(0, 1.5)), np.zeros(A)], axis=1)
+            obs[m] = box.reshape(A, 2, 4).transpose(1, 0, 2)
+            kinds[m] = rng.choice([6, 7])
     return state, u_ref, np.ascontiguousarray(obs), kinds
 
 

@@ -43,9 +43,10 @@ def advance(obs, ty, dt):
     k = np.broadcast_to(ty.reshape(M, -1), (M, A))
     e, c, r = k == _lib.OBS_ELLIPSE, k == _lib.OBS_CONE, k == _lib.OBS_RADIAL
     ep, cp = k == _lib.OBS_ELLIPSE_PREP, k == _lib.OBS_CONE_PREP   # prepared forms: velocities stored resolved
+    cb = k == _lib.OBS_CONE_BOX                                     # a cone made of a box: along x at the box's speed
     ang = obs[:, 0, :, 2] + obs[:, 1, :, 1]
     dx = np.where(e, obs[:, 1, :, 1], np.where(c, obs[:, 0, :, 3] * np.cos(ang), np.where(r, obs[:, 1, :, 0],
-                  np.where(ep, obs[:, 1, :, 2], np.where(cp, obs[:, 0, :, 2], 0.0)))))
+                  np.where(ep, obs[:, 1, :, 2], np.where(cp, obs[:, 0, :, 2], np.where(cb, obs[:, 1, :, 1], 0.0))))))
     dy = np.where(e, obs[:, 1, :, 2], np.where(c, obs[:, 0, :, 3] * np.sin(ang), np.where(r, obs[:, 1, :, 1],
                   np.where(ep, obs[:, 1, :, 3], np.where(cp, obs[:, 0, :, 3], 0.0)))))
     obs[:, 0, :, 0] += dx * dt
@@ -56,7 +57,8 @@ def seek(obs, ty, xy, dt, k, v_min):
     """SCCBF_MOTION_SEEKER with per-agent kinds: the oracle's seeker step slot by slot."""
     M, A = obs.shape[0], obs.shape[2]
     kk = np.broadcast_to(ty.reshape(M, -1), (M, A))
-    for kind in (_lib.OBS_ELLIPSE, _lib.OBS_RADIAL, _lib.OBS_CONE, _lib.OBS_ELLIPSE_PREP, _lib.OBS_CONE_PREP):
+    for kind in (_lib.OBS_ELLIPSE, _lib.OBS_RADIAL, _lib.OBS_CONE, _lib.OBS_ELLIPSE_PREP, _lib.OBS_CONE_PREP,
+                 _lib.OBS_CONE_BOX):
         tmp = obs.copy()
         orc.seeker_step(tmp, np.full(M, kind, dtype=np.uint8), xy, dt, k=k, v_min=v_min)
         sel = kk == kind

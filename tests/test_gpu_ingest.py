@@ -153,3 +153,59 @@ def test_perception_to_filter_on_the_device(oracle, dtype):
             ok = (sg == 0) & (so == 0) & (np.abs(uo[:, 1]) < 1.2)
             err = np.abs(ug - uo).max(axis=1) / np.maximum(1, np.abs(uo).max(axis=1))
             assert np.quantile(err[ok], 0.99) <= 2e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("dyn", ["dbm", "kbm", "dum", "sadbm"])
+@pytest.mark.parametrize("M", [6, 40, 150])
+def test_boxes_as_slots_equal_ingestion_then_filter(oracle, dtype, dyn, M):
+    """Kinds 6, 7 (the slot is the bounding box + buffer, no ingestion pass): the answers of ingest_bbox followed by
+    the filter, in both layouts and for every model and kernel family: ellipse rows bit for bit, cone rows to the last
+    few bits (the compiler fuses multiply-adds differently where it knows the cone's heading to be zero), the inputs
+    accordingly; and the oracle's answers."""
+    from sccav_cbf_amd.ingest import bbox_as_obs
+    from tests import parity
+    A = 1500
+    bbox, rng = _boxes(A, M, 33 + M)
+    state = np.stack([rng.uniform(-5, 5, A), rng.uniform(-1, 1, A), rng.normal(0, 0.3, A), rng.uniform(3, 12, A)], axis=1)
+    bbox[:, 0, :, 0] = state[None, :, 0] + rng.uniform(8, 60, (M, A))
+    bbox[:, 0, :, 1] = state[None, :, 1] + rng.uniform(-8, 8, (M, A))
+    kind = rng.choice(np.array([0, 1, 255], dtype=np.uint8), M, p=[0.45, 0.45, 0.1])
+    u_ref = np.stack([rng.normal(0, 0.5, A) + (6.0 if dyn == "kbm" else 0.0), rng.normal(0, 0.05, A)], axis=1)
+    t = lambda v: torch.from_numpy(np.ascontiguousarray(v)).to(DEV).to(dtype)     # noqa: E731
+    kd = torch.from_numpy(kind).to(DEV)
+    f = BatchedCBF(alpha=1.0, R=np.diag([0.5, 0.5]), dynamics=dyn)
+    kw = lambda: dict(slip=torch.full((A, 2), 0.05, dtype=dtype, device=DEV), dt=0.05) if dyn == "sadbm" else {}   # noqa: E731
+    boxes, kb = bbox_as_obs(t(bbox), kd, buffer=0.6)
+    assert set(kb.cpu().tolist()) <= {6, 7, 255}
+    eps = 1e-13 if dtype == torch.float64 else 1e-6
+    for tiled in (False, True):
+        slots = ingest_bbox(t(bbox), kd, buffer=0.6, tiled=tiled)
+        k0, k1 = kw(), kw()
+        u0, s0, r0 = f.solve(t(state), t(u_ref), slots, kd, want_rows=True, **k0)
+        u1, s1, r1 = f.solve(t(state), t(u_ref), planes_to_tiled(boxes) if tiled else boxes, kb, want_rows=True, **k1)
+        torch.cuda.synchronize()
+        assert torch.equal(r0[kd == 0], r1[kd == 0])
+        scale = r0.abs().amax(dim=2, keepdim=True) + 1.0
+        # (a cone that closes at a small relative speed divides by it: a last-bit difference upstream is magnified)
+        dr = ((r0 - r1).abs() / scale).double().cpu().numpy()
+        assert np.quantile(dr, 0.999) <= 32 * eps and dr.max() <= (1e-10 if dtype == torch.float64 else 1e-3)
+        assert int((s0 != s1).sum()) <= A // 1000
+        r0n, u0n, u1n = r0.double().cpu().numpy(), u0.double().cpu().numpy(), u1.double().cpu().numpy()
+        # a vertex of two rows moves by (row difference) / |sin| of their angle: rows a few ulp apart, |sin| >= 1e-2
+        well = ((s0 == 0) & (s1 == 0)).cpu().numpy() & (parity.active_det(u0n, r0n) >= 1e-2)
+        du = np.abs(u0n - u1n).max(axis=1) / np.maximum(1.0, np.abs(u0n).max(axis=1))
+        assert well.sum() > 50
+        if dtype == torch.float64:
+            assert du[well].max() <= 1e-9
+        else:   # (the conditioning estimate is in the QP's own coordinates only for slip-angle inputs: a quantile)
+            assert np.quantile(du[well], 0.99) <= 1e-4 and du[well].max() <= 0.1
+        if dyn == "sadbm":
+            assert float((k0["slip"] - k1["slip"]).abs()[torch.from_numpy(well).to(DEV)].max()) <= 1e3 * eps
+    if dyn in ("dbm", "kbm") and dtype == torch.float64:
+        boxed = bbox.copy()
+        boxed[:, 1, :, 2] = 0.6
+        p = oracle.make_params(alpha=1.0, R=(0.5, 0, 0, 0.5), dynamics=oracle.DYN_KBM if dyn == "kbm" else oracle.DYN_DBM)
+        uo, so, _ = oracle.solve_batch(p, state, u_ref, boxed, kb.cpu().numpy(), want_rows=True)
+        assert np.array_equal(s1.cpu().numpy(), so)
+        assert (np.abs(u1.cpu().numpy() - uo).max(axis=1) / np.maximum(1, np.abs(uo).max(axis=1))).max() <= 1e-7

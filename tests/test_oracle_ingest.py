@@ -60,3 +60,35 @@ def test_ingest_bbox_by_hand(oracle):
     assert np.allclose(obs[0].reshape(-1), [10.0, -3.0, 2.5, 1.5, 0.4, 0, 0, 0])
     assert np.allclose(obs[1].reshape(-1), [10.0, -3.0, 0.0, 3.0, np.hypot(2.0, 1.0) + 0.5, 0, 0, 0])
     assert not obs[2].any()
+
+
+def test_box_kinds_equal_ingested_slots(oracle):
+    """Kinds 6, 7: the slot is the bounding box itself (+ buffer); the rows are those of the obstacle that
+    from_bounding_box makes of it (cbf/obstacles.py:320-331, 534-543), for every model."""
+    rng = np.random.default_rng(5)
+    A, M = 300, 6
+    bbox = np.zeros((M, 2, A, 4))
+    state = np.stack([rng.uniform(-5, 5, A), rng.uniform(-1, 1, A), rng.normal(0, 0.3, A), rng.uniform(3, 12, A)], axis=1)
+    bbox[:, 0, :, 0] = state[None, :, 0] + rng.uniform(6, 40, (M, A))
+    bbox[:, 0, :, 1] = state[None, :, 1] + rng.uniform(-6, 6, (M, A))
+    bbox[:, 0, :, 2] = rng.uniform(1.5, 3.0, (M, A))
+    bbox[:, 0, :, 3] = rng.uniform(0.7, 1.2, (M, A))
+    bbox[:, 1, :, 0] = rng.uniform(-np.pi, np.pi, (M, A))
+    bbox[:, 1, :, 1] = rng.uniform(0, 8, (M, A))
+    kind = np.array([0, 1, 0, 1, 1, 255], dtype=np.uint8)
+    slots = oracle.ingest_bbox(bbox, kind, buffer=0.7)
+    boxed = bbox.copy()
+    boxed[:, 1, :, 2] = 0.7
+    kind_box = np.array([6, 7, 6, 7, 7, 255], dtype=np.uint8)
+    u_ref = np.stack([rng.normal(0, 0.5, A), rng.normal(0, 0.05, A)], axis=1)
+    for dyn in (oracle.DYN_DBM, oracle.DYN_KBM, oracle.DYN_DUM):
+        p = oracle.make_params(alpha=1.0, R=(0.5, 0, 0, 0.5), dynamics=dyn)
+        u0, s0, r0 = oracle.solve_batch(p, state, u_ref, slots, kind, want_rows=True)
+        u1, s1, r1 = oracle.solve_batch(p, state, u_ref, boxed, kind_box, want_rows=True)
+        assert np.array_equal(s0, s1) and np.array_equal(u0, u1) and np.array_equal(r0, r1)
+    p = oracle.make_params(alpha=1.0, R=(0.5, 0, 0, 0.5), dynamics=oracle.DYN_SADBM, flags=oracle.FLAG_CONE_BETA_STATE)
+    slip0 = np.stack([rng.uniform(-0.2, 0.2, A), rng.uniform(-0.2, 0.2, A)], axis=1)
+    sa, sb = slip0.copy(), slip0.copy()
+    u0, s0, _ = oracle.solve_sa_batch(p, 0.05, state, sa, u_ref, slots, kind, want_rows=True)
+    u1, s1, _ = oracle.solve_sa_batch(p, 0.05, state, sb, u_ref, boxed, kind_box, want_rows=True)
+    assert np.array_equal(s0, s1) and np.array_equal(u0, u1) and np.array_equal(sa, sb)
