@@ -138,8 +138,8 @@ typedef struct sccbf_params {
     double zero_tol;      /* 1e-3 in the reference */
     int32_t dynamics;     /* SCCBF_DYN_* */
     int32_t lanes_per_qp; /* 0 = choose; 1,2,4,8,16 = register-resident rows with that
-                             many cooperating lanes per QP (M <= 16 lanes); 16 with M > 256,
-                             32, 64 = rows staged in LDS only, any M <= SCCBF_MAX_ROWS whose
+                             many cooperating lanes per QP (M <= 16 lanes, and <= 128); 16 with
+                             M > 128, 32, 64 = rows staged in LDS only, any M <= SCCBF_MAX_ROWS whose
                              tables fit (64 / lanes tables of 3 M values per wavefront, 64 KB):
                              64 = one wavefront per QP */
     uint32_t flags;       /* SCCBF_FLAG_* */

@@ -32,7 +32,7 @@ class BatchedCBF:
     (u = [a, omega], no steering transform) or "sadbm" = SADBM_CBF_2DS (u = [a, delta] in and
     out, the QP works on [a, d(beta)/dt]; solve() then needs `slip` and `dt`).
     lanes_per_qp: 0 lets the library choose; 1/2/4/8/16 cooperating lanes per QP
-    with rows in registers; 16 beyond 256 rows, 32, 64 = rows in LDS only (64 = one wavefront per QP).
+    with rows in registers; 16 beyond 128 rows, 32, 64 = rows in LDS only (64 = one wavefront per QP).
     """
 
     def __init__(self, alpha=1.0, lr=1.45, lf=1.45, L=2.9, R=None, dynamics="dbm",

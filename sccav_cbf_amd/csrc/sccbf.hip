@@ -152,11 +152,12 @@ template <typename T, int G> struct WaveShape {
 
 template <typename T> size_t wave_lds(int M, int qpb) { return wave_lds_bytes<T>(M, qpb); }
 
-// lanes per QP when the library chooses (measured at 65536 agents, fp32, 257 ... 1024 rows): 32 while four
-// of its workgroups fit a CU (16 wavefronts), else a wavefront per QP, whose workgroups have twice the
-// wavefronts for the same tables
+// lanes per QP when the library chooses (measured at 65536 agents, fp32, 129 ... 1024 rows): the narrowest
+// group of which four workgroups still fit a CU (16 lanes up to 213 fp32 rows, 32 up to 416), else a
+// wavefront per QP, whose workgroups have twice the wavefronts for the same tables
 template <typename T> int wave_lanes(int M)
 {
+    if (wave_lds<T>(M, WaveShape<T, 16>::kQpb) * 4 <= kLdsPerCu) return 16;
     if (wave_lds<T>(M, WaveShape<T, 32>::kQpb) * 4 <= kLdsPerCu) return 32;
     return 64;
 }
@@ -228,7 +229,7 @@ int dispatch(const sccbf_params* sp, KArgs<T>& k, void* stream)
     case 2: return launch_group_rpl<T, QP_ONLY, 2>(k, s);
     case 4: return launch_group_rpl<T, QP_ONLY, 4>(k, s);
     case 8: return launch_group_rpl<T, QP_ONLY, 8>(k, s);
-    case 16: return k.M <= 256 ? launch_group_rpl<T, QP_ONLY, 16>(k, s) : launch_wave<T, QP_ONLY, 16>(k, s);
+    case 16: return k.M <= 128 ? launch_group_rpl<T, QP_ONLY, 16>(k, s) : launch_wave<T, QP_ONLY, 16>(k, s);
     case 32: return launch_wave<T, QP_ONLY, 32>(k, s);
     case 64: return launch_wave<T, QP_ONLY, 64>(k, s);
     default: return SCCBF_ERR_VARIANT;
@@ -284,7 +285,7 @@ int dispatch_ext(const sccbf_params* sp, const KArgs<T>& k, const XArgs<T>& x, v
     }
     if (lanes == 4 && k.M <= 64) return launch_ext_rpl<T, 4>(k, x, s);
     if (lanes == 8 && k.M <= 128) return launch_ext_rpl<T, 8>(k, x, s);
-    if (lanes == 16) return k.M <= 256 ? launch_ext_rpl<T, 16>(k, x, s) : launch_wave_ext<T, 16>(k, x, s);
+    if (lanes == 16) return k.M <= 128 ? launch_ext_rpl<T, 16>(k, x, s) : launch_wave_ext<T, 16>(k, x, s);
     if (lanes == 32) return launch_wave_ext<T, 32>(k, x, s);
     if (lanes == 64) return launch_wave_ext<T, 64>(k, x, s);
     return SCCBF_ERR_VARIANT;

@@ -356,7 +356,7 @@ def _many_rows(A, M, seed):
 
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
 @pytest.mark.parametrize("M,lanes", [(_lib.MAX_ROWS, 0), (800, 32), (_lib.MAX_ROWS, 64), (400, 16), (257, 16),
-                                     (300, 0), (700, 0), (129, 0), (900, 0)])
+                                     (300, 0), (700, 0), (129, 0), (900, 0), (150, 0), (200, 16), (129, 32)])
 def test_rows_in_lds_only_up_to_the_maximum_row_count(oracle, M, lanes, dtype):
     """More rows than the register-resident kernels take, up to M = SCCBF_MAX_ROWS: rows staged in LDS only,
     16 or 32 lanes or a whole wavefront per QP; batches that end inside a workgroup and inside a pair of them."""
