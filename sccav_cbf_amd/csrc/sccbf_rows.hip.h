@@ -263,8 +263,18 @@ __device__ inline void contract_row_(const Partials<T>& d, const Ego<T>& e, cons
 
 // Barrier value and partials of one slot whose kind is known; false for an empty slot.
 template <typename T>
-__device__ inline bool slot_partials_(int type, const T o[8], const Ego<T>& e, const KArgs<T>& p, Partials<T>& d)
+__device__ inline bool slot_partials_(int type, const T o_in[8], const Ego<T>& e, const KArgs<T>& p, Partials<T>& d)
 {
+    T o[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = o_in[i];
+    if (type == SCCBF_OBS_ELLIPSE_BOX) {         // the obstacle the box stands for: the ellipse as written,
+        box_ellipse_(o_in, o);
+        type = SCCBF_OBS_ELLIPSE;
+    } else if (type == SCCBF_OBS_CONE_BOX) {     // the cone with its velocity (speed, 0) resolved
+        box_cone_prep_(o_in, o);
+        type = SCCBF_OBS_CONE_PREP;
+    }
     switch (type) {
     case SCCBF_OBS_ELLIPSE: ellipse_(e.x, e.y, o, d); return true;
     case SCCBF_OBS_CONE: cone_(e.x, e.y, e.th, e.v, e.cth, e.sth, o, p.zero_tol, d); return true;
@@ -272,18 +282,6 @@ __device__ inline bool slot_partials_(int type, const T o[8], const Ego<T>& e, c
     case SCCBF_OBS_RADIAL: radial_(e.x, e.y, e.v, o, d); return true;
     case SCCBF_OBS_ELLIPSE_PREP: ellipse_prep_(e.x, e.y, o, d); return true;
     case SCCBF_OBS_CONE_PREP: cone_prep_(e.x, e.y, e.th, e.v, e.cth, e.sth, o, p.zero_tol, d); return true;
-    case SCCBF_OBS_ELLIPSE_BOX: {
-        T q[8];
-        box_ellipse_(o, q);
-        ellipse_(e.x, e.y, q, d);
-        return true;
-    }
-    case SCCBF_OBS_CONE_BOX: {
-        T q[8];
-        box_cone_prep_(o, q);
-        cone_prep_(e.x, e.y, e.th, e.v, e.cth, e.sth, q, p.zero_tol, d);
-        return true;
-    }
     default: return false;
     }
 }
