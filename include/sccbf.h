@@ -141,7 +141,9 @@ typedef struct sccbf_params {
                              many cooperating lanes per QP (M <= 16 lanes, and <= 128); 16 with
                              M > 128, 32, 64 = rows staged in LDS only, any M <= SCCBF_MAX_ROWS whose
                              tables fit (64 / lanes tables of 3 M values per wavefront, 64 KB):
-                             64 = one wavefront per QP */
+                             64 = one wavefront per QP.  Tables beyond 64 KB per workgroup need a
+                             function attribute that the first such launch on a device sets
+                             (hipFuncSetAttribute): make that launch outside stream capture */
     uint32_t flags;       /* SCCBF_FLAG_* */
     int32_t reserved;
 } sccbf_params;
