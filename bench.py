@@ -141,9 +141,15 @@ def _profile_json(name):
         return None
 
 
-def _time_graph(walk, stream, n_per_walk, reps, graph=True):
+def _time_graph(walk, stream, n_per_walk, reps, graph=True, branches=1):
     """ms per launch of walk() (n_per_walk launches) replayed from a hipGraph on `stream` (or launched
-    eagerly, graph=False: a profiler then sees every launch)."""
+    eagerly, graph=False: a profiler then sees every launch).  walk may be a list of n_per_walk independent
+    launches instead: with branches > 1 they are dealt to that many parallel branches of the graph."""
+    steps = walk if isinstance(walk, (list, tuple)) else None
+    if steps is not None:
+        def walk():
+            for f in steps:
+                f()
     walk()
     torch.cuda.synchronize()
 
@@ -152,8 +158,18 @@ def _time_graph(walk, stream, n_per_walk, reps, graph=True):
     g = _Eager
     if graph:
         g = torch.cuda.CUDAGraph()
+        side = [torch.cuda.Stream(stream.device) for _ in range(branches - 1)] if steps is not None else []
         with torch.cuda.graph(g, stream=stream):
-            walk()
+            if side:
+                for s2 in side:
+                    s2.wait_stream(stream)
+                for i, f in enumerate(steps):
+                    with torch.cuda.stream(([stream] + side)[i % branches]):
+                        f()
+                for s2 in side:
+                    stream.wait_stream(s2)
+            else:
+                walk()
     for _ in range(reps):   # the GPU idled while the host built the batch: let the clocks come back
         g.replay()
     torch.cuda.synchronize()
@@ -185,15 +201,18 @@ def large_batch(flt, device, layout, slots, agents=1 << 20, n=3, reps=200, graph
     ty = torch.from_numpy(w["obs_type"]).to(device)
     st = torch.cuda.Stream(device)
     with torch.cuda.stream(st):
-        def walk():
-            for b in ring:
-                flt.solve(b["state"], b["u_ref"], b["obs"], ty, u_out=b["u_out"], status=b["status"])
-        ms = _time_graph(walk, st, n, reps, graph=graph)
+        def launch(b):
+            return lambda: flt.solve(b["state"], b["u_ref"], b["obs"], ty, u_out=b["u_out"], status=b["status"])
+        steps = [launch(b) for b in ring]
+        ms = _time_graph(steps, st, n, reps, graph=graph)
     ab = algorithmic_bytes(agents, ROWS)
-    return {"agents": agents, "kernel_ms": ms, "solves_per_s": agents / (ms * 1e-3),
-            "achieved_GBps": ab / (ms * 1e-3) / 1e9, "frac": ab / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-            "algorithmic_bytes_per_launch": ab, "traffic": _profile_json("traffic_large.json"),
-            "launches": reps * n}
+    out = {"agents": agents, "kernel_ms": ms, "solves_per_s": agents / (ms * 1e-3),
+           "achieved_GBps": ab / (ms * 1e-3) / 1e9, "frac": ab / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+           "algorithmic_bytes_per_launch": ab, "traffic": _profile_json("traffic_large.json"),
+           "launches": reps * n,
+           # (three overlapping launches of this size measured slower: 95.7 us per launch)
+           "launch": "one at a time (serial hipGraph)" if graph else "eager"}
+    return out
 
 
 def fp64_lines(device):
@@ -220,14 +239,17 @@ def fp64_lines(device):
                 u_out=torch.empty((A, 2), dtype=torch.float64, device=device),
                 status=torch.empty((A,), dtype=torch.int32, device=device)))
 
-        def walk():
-            for b in ring:
-                flt.solve(b["state"], b["u_ref"], b["obs"], ty, u_out=b["u_out"], status=b["status"])
-        ms = _time_graph(walk, st, n, 40)
+        def launch(b):
+            return lambda: flt.solve(b["state"], b["u_ref"], b["obs"], ty, u_out=b["u_out"], status=b["status"])
+        steps = [launch(b) for b in ring]
+        ms1 = _time_graph(steps, st, n, 40)
+        ms = _time_graph(steps, st, n, 40, branches=4)
         ab = algorithmic_bytes(A, M, w=8)
         out["c5"] = {"workload": "C5 fp64: %d agents x %d rows (2 lanes + 6 cones)" % (A, M), "kernel_ms": ms,
+                     "launch": "hipGraph of %d launches in 4 parallel branches (independent batches)" % n,
                      "solves_per_s": A / (ms * 1e-3), "algorithmic_bytes_per_launch": ab,
-                     "achieved_GBps": ab / (ms * 1e-3) / 1e9, "frac": ab / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+                     "achieved_GBps": ab / (ms * 1e-3) / 1e9, "frac": ab / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                     "one_at_a_time": {"kernel_ms": ms1, "frac": ab / (ms1 * 1e-3) / 1e9 / HBM_PEAK_GBPS}}
         del ring
         w = scenarios.radial_seekers(M=32)
         t = {k: torch.from_numpy(v).to(device) for k, v in w.items()}
@@ -397,16 +419,31 @@ def worker(args):
     else:
         stream = torch.cuda.Stream(device)
         with torch.cuda.stream(stream):
-            # launches per captured walk: whole walks over the ring, one replay for a short timed region
+            # launches per captured walk: whole walks over the ring, one replay for a short timed region.
+            # The steps are independent (every step has its own batch and its own outputs), so the captured
+            # walk deals them to `branches` parallel branches of the graph (side streams forked from and joined
+            # to the capture stream): while one launch waits for its data another one computes.
             glen = RING * max(1, -(-min(max(args.steps, 10), 100) // RING))
+            nb = 1 if args.no_graph else max(1, args.branches)
+            side = [torch.cuda.Stream(device) for _ in range(nb - 1)]
             for i in range(glen):
                 step(i)
             torch.cuda.synchronize()
+
+            def capture(branches, n=None):
+                g = torch.cuda.CUDAGraph()
+                lanes = [stream] + side[:branches - 1]
+                with torch.cuda.graph(g, stream=stream):
+                    for s2 in lanes[1:]:
+                        s2.wait_stream(stream)
+                    for i in range(n or glen):
+                        with torch.cuda.stream(lanes[i % branches]):
+                            step(i)
+                    for s2 in lanes[1:]:
+                        stream.wait_stream(s2)
+                return g
             if not args.no_graph:
-                graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph, stream=stream):
-                    for i in range(glen):
-                        step(i)
+                graph = capture(nb)
 
             def run(k):
                 done = 0
@@ -435,6 +472,43 @@ def worker(args):
             t1 = time.perf_counter()
             wall = t1 - t0
             dev_ms = ev0.elapsed_time(ev1)
+            # the same steps one at a time (a serial graph), outside the timed region: what a caller whose
+            # launches depend on each other gets, and what a per-kernel profile shows; and the proof that the
+            # overlapped walk wrote the same answers
+            serial_ms = None
+            if graph is not None and nb > 1:
+                got = [(b["u_out"].clone(), b["status"].clone()) for b in ring]
+                g1 = capture(1)
+                n1 = max(2, min(20, 2000 // glen))
+                for _ in range(n1):
+                    g1.replay()
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                for _ in range(n1):
+                    g1.replay()
+                e1.record(stream)
+                torch.cuda.synchronize()
+                serial_ms = e0.elapsed_time(e1) / (n1 * glen)
+                same_answers = all(torch.equal(u, b["u_out"]) and torch.equal(st, b["status"])
+                                   for (u, st), b in zip(got, ring))
+            # a timed region of a few hundred steps is mostly the start of one graph and the closing
+            # synchronize: the same measurement over 20000 steps, outside the timed region, beside it
+            steady = None
+            if graph is not None and args.steps < 5000:
+                g100 = capture(nb, 10 * RING)
+                for _ in range(50):
+                    g100.replay()
+                torch.cuda.synchronize()
+                n_st = 200
+                ts = time.perf_counter()
+                for _ in range(n_st):
+                    g100.replay()
+                torch.cuda.synchronize()
+                st_ms = (time.perf_counter() - ts) * 1e3 / (n_st * 10 * RING)
+                steady = {"steps": n_st * 10 * RING, "ms_per_step": st_ms, "value": A / (st_ms * 1e-3),
+                          "launch": "hipGraphs of %d launches in %d parallel branch(es)" % (10 * RING, nb),
+                          "note": "this rank, wall clock, outside the timed region"}
 
     # max over ranks of the timed region; every rank's own time; proof that the collective
     # library saw every rank (a sum of ones over the process group)
@@ -492,8 +566,12 @@ def worker(args):
                        "obs_layout": layout_name,
                        "obs_slots": "prepared (kinds 4, 5: 1/a^2, 1/b^2, cos, sin and the cone's obstacle velocity "
                                     "stored in the slot)" if args.slots == "prepared" else "as written (kinds 0, 1)",
-                       "launch": "eager" if graph is None else "hipGraph of %d launches" % glen,
+                       "launch": "eager" if graph is None else ("hipGraph of %d launches" % glen if nb == 1 else
+                                                                "hipGraph of %d launches in %d parallel branches (the steps "
+                                                                "are independent batches: their launches overlap)" % (glen, nb)),
                        "clock_ramp_steps_before_warmup": ramp_steps},
+            # achieved = algorithmic bytes of the timed region's launches / its device time (HIP events); with
+            # overlapping launches kernel_ms is the time per launch of the walk, not one kernel's own duration
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": _profile_json("traffic.json"),
                          "kernel_ms": kern_ms,
@@ -503,6 +581,17 @@ def worker(args):
             # QPs whose rows admit no input: the filter reports status 1 and hands back the nominal input
             "infeasible_fraction": float(counts[1]) / max(1, int(counts.sum())),
         }
+        if not stub and serial_ms is not None:
+            out["roofline"]["concurrent_launches"] = nb
+            out["roofline"]["one_at_a_time"] = {
+                "kernel_ms": serial_ms, "achieved": abytes / (serial_ms * 1e-3) / 1e9,
+                "frac": abytes / (serial_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                "note": "the same launches from a serial graph: one kernel's own duration, what rocprofv3 "
+                        "--kernel-trace shows per kernel and what a chain of dependent launches gets"}
+            out["roofline"]["overlapped_answers_equal_serial"] = bool(same_answers)
+        if not stub and steady is not None:
+            steady["roofline_frac"] = abytes / (steady["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBPS
+            out["steady_state"] = steady
         if stub:
             out["data"] = "none (cpu stub: launcher rehearsal, nothing measured)"
             out["stub"] = True
@@ -553,6 +642,8 @@ def main():
                          "reference's objects hold them; 8 scalars per slot either way")
     ap.add_argument("--no-stream-hint", action="store_true",
                     help="do not tell the library that each step's obstacle slots are read once (SCCBF_FLAG_OBS_STREAMED)")
+    ap.add_argument("--branches", type=int, default=3,
+                    help="parallel branches of the captured walk (independent steps overlap); 1 = one launch at a time")
     ap.add_argument("--ring", type=int, default=RING,
                     help="distinct batches the steps walk over (default 10: more than the Infinity Cache holds, every "
                          "step streams from HBM; 1: the same batch every step, served from the Infinity Cache, which "
