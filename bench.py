@@ -157,19 +157,8 @@ def _time_graph(walk, stream, n_per_walk, reps, graph=True, branches=1):
         replay = staticmethod(walk)
     g = _Eager
     if graph:
-        g = torch.cuda.CUDAGraph()
-        side = [torch.cuda.Stream(stream.device) for _ in range(branches - 1)] if steps is not None else []
-        with torch.cuda.graph(g, stream=stream):
-            if side:
-                for s2 in side:
-                    s2.wait_stream(stream)
-                for i, f in enumerate(steps):
-                    with torch.cuda.stream(([stream] + side)[i % branches]):
-                        f()
-                for s2 in side:
-                    stream.wait_stream(s2)
-            else:
-                walk()
+        from sccav_cbf_amd.batched import capture_independent
+        g = capture_independent(steps if steps is not None else [walk], branches if steps is not None else 1, stream)
     for _ in range(reps):   # the GPU idled while the host built the batch: let the clocks come back
         g.replay()
     torch.cuda.synchronize()
@@ -425,23 +414,13 @@ def worker(args):
             # to the capture stream): while one launch waits for its data another one computes.
             glen = RING * max(1, -(-min(max(args.steps, 10), 100) // RING))
             nb = 1 if args.no_graph else max(1, args.branches)
-            side = [torch.cuda.Stream(device) for _ in range(nb - 1)]
             for i in range(glen):
                 step(i)
             torch.cuda.synchronize()
 
             def capture(branches, n=None):
-                g = torch.cuda.CUDAGraph()
-                lanes = [stream] + side[:branches - 1]
-                with torch.cuda.graph(g, stream=stream):
-                    for s2 in lanes[1:]:
-                        s2.wait_stream(stream)
-                    for i in range(n or glen):
-                        with torch.cuda.stream(lanes[i % branches]):
-                            step(i)
-                    for s2 in lanes[1:]:
-                        stream.wait_stream(s2)
-                return g
+                from sccav_cbf_amd.batched import capture_independent
+                return capture_independent([(lambda i=i: step(i)) for i in range(n or glen)], branches, stream)
             if not args.no_graph:
                 graph = capture(nb)
 

@@ -131,3 +131,43 @@ def test_c2_radial_closed_loop(oracle):
     assert worst <= 1e-8
     assert modified > 10
     print("C2: ticks with intervention %d, infeasible %d, worst |du| %.2e" % (modified, infeasible, worst))
+
+
+def test_independent_launches_in_parallel_graph_branches(oracle):
+    """batched.capture_independent: the batches of a sweep captured on three parallel branches of one hipGraph give
+    the answers of the same launches one at a time, on every replay, with eager work and synchronisations between
+    the replays."""
+    from sccav_cbf_amd import scenarios
+    from sccav_cbf_amd.batched import BatchedCBF, capture_independent, planes_to_tiled
+    dev = torch.device("cuda:0")
+    flt = BatchedCBF(alpha=1.0, R=np.diag([0.5, 0.5]), streamed_obs=True)
+    batches = []
+    for b in range(7):
+        w = scenarios.prepared(scenarios.config4(A=4096 + 64 * b, nominal="uniform", seed=40 + b))
+        t = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in w.items()}
+        t = {k: (v.float() if v.dtype.is_floating_point else v) for k, v in t.items()}
+        t["obs"] = planes_to_tiled(t["obs"])
+        A = t["state"].shape[0]
+        t["u"] = torch.zeros((A, 2), device=dev)
+        t["st"] = torch.full((A,), -1, dtype=torch.int32, device=dev)
+        batches.append(t)
+
+    def launch(t):
+        return lambda: flt.solve(t["state"], t["u_ref"], t["obs"], t["obs_type"], u_out=t["u"], status=t["st"])
+    steps = [launch(t) for t in batches]
+    for f in steps:
+        f()
+    torch.cuda.synchronize()
+    want = [(t["u"].clone(), t["st"].clone()) for t in batches]
+    s = torch.cuda.Stream(dev)
+    with torch.cuda.stream(s):
+        g = capture_independent(steps, branches=3)
+        for rep in range(4):
+            for t in batches:                      # eager work between the replays: the outputs are wiped
+                t["u"].fill_(float(rep))
+                t["st"].fill_(-7)
+            torch.cuda.synchronize()
+            g.replay()
+            torch.cuda.synchronize()
+            for (u, st), t in zip(want, batches):
+                assert torch.equal(u, t["u"]) and torch.equal(st, t["st"]), rep
