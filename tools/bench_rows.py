@@ -25,6 +25,8 @@ def main():
     ap.add_argument("--lanes", default="0", help="lanes_per_qp values to try (0: the library's choice)")
     ap.add_argument("--models", default="dbm,kbm,dum,sadbm")
     ap.add_argument("--sorted", action="store_true", help="slots grouped by kind instead of 8 + 8 repeated")
+    ap.add_argument("--branches", type=int, default=1,
+                    help="parallel branches of the captured walk: the launches are independent batches")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     A = args.agents
@@ -76,9 +78,13 @@ def main():
                 print("M %4d %-6s lanes %2d: %s" % (M, name, lanes, str(exc)[:60]), flush=True)
                 continue
             torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                walk()
+            from sccav_cbf_amd.batched import capture_independent
+            outs = [(torch.empty_like(u), torch.empty_like(st)) for _ in ring * inner]   # launches may overlap
+            steps = [(lambda b=b, o=o: f.solve(b["state"], b["u_ref"], b["obs"], ty, u_out=o[0], status=o[1], **kw))
+                     for b, o in zip(ring * inner, outs)]
+            cs = torch.cuda.Stream(dev)
+            with torch.cuda.stream(cs):
+                g = capture_independent(steps, args.branches)
             n = max(3, min(100, int(4e9 // abytes)))
             for _ in range(n):
                 g.replay()
@@ -91,7 +97,7 @@ def main():
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 1e3 / (nring * inner * n)
             print("M %4d %-6s lanes %2d %9.2f us per launch  %.3f of 8 TB/s  infeasible %.2f" %
-                  (M, name, lanes, us, abytes / (us * 1e-6) / 8e12, float((st == 1).float().mean())), flush=True)
+                  (M, name, lanes, us, abytes / (us * 1e-6) / 8e12, float((outs[0][1] == 1).float().mean())), flush=True)
         del ring
         torch.cuda.empty_cache()
 
