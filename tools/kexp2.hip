@@ -1,5 +1,5 @@
 // kexp2.hip - stand-alone load-pattern experiments (not part of the library).
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tools/kexp2 tools/kexp2.hip && tools/kexp2 [ring]
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tools/kexp2 tools/kexp2.hip && tools/kexp2 [ring [streams]]
 // Every kernel reads the same 32 MiB (65536 agents x 16 slots x 32 B) and writes 12 B per agent; the
 // variants differ in how the bytes are spread over wavefronts and load instructions.  Each wavefront
 // stamps its start and end with the 100 MHz wall clock, so the in-kernel time (first start -> last end)
@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -91,6 +92,9 @@ template <int U> __global__ __launch_bounds__(256) void k_stream(const float4* _
 int main(int argc, char** argv)
 {
     const int RING = argc > 1 ? atoi(argv[1]) : 10;
+    const int NS = argc > 2 ? atoi(argv[2]) : 1;  // streams the launches are dealt to (independent launches overlap)
+    std::vector<hipStream_t> streams(NS);
+    for (int i = 0; i < NS; ++i) CK(hipStreamCreate(&streams[i]));
     const long long N4 = 65536LL * 16 * 2;  // float4 elements: 32 MiB
     std::vector<float4*> in(RING);
     std::vector<float> h(N4 * 4);
@@ -110,16 +114,24 @@ int main(int argc, char** argv)
     CK(hipEventCreate(&e1));
     printf("ring %d (%s)\n", RING, RING * 32 > 256 ? "HBM" : "Infinity Cache");
 
+    hipStream_t cur = 0;
     auto run = [&](const char* name, int waves, auto launch) {
-        for (int i = 0; i < 3 * RING + 20; ++i) launch(i % RING);
+        for (int i = 0; i < 3 * RING + 20; ++i) { cur = NS > 1 ? streams[i % NS] : 0; launch(i % RING); }
         CK(hipDeviceSynchronize());
-        const int iters = 300;
-        CK(hipEventRecord(e0, 0));
-        for (int i = 0; i < iters; ++i) launch(i % RING);
-        CK(hipEventRecord(e1, 0));
-        CK(hipEventSynchronize(e1));
+        const int iters = NS > 1 ? 3000 : 300;
         float ms;
-        CK(hipEventElapsedTime(&ms, e0, e1));
+        if (NS > 1) {  // several streams: wall clock around the launches and the final synchronize
+            const auto t0 = std::chrono::steady_clock::now();
+            for (int i = 0; i < iters; ++i) { cur = streams[i % NS]; launch(i % RING); }
+            CK(hipDeviceSynchronize());
+            ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        } else {
+            CK(hipEventRecord(e0, 0));
+            for (int i = 0; i < iters; ++i) launch(i % RING);
+            CK(hipEventRecord(e1, 0));
+            CK(hipEventSynchronize(e1));
+            CK(hipEventElapsedTime(&ms, e0, e1));
+        }
         double in_kernel = 0, p50end = 0, p10end = 0;
         if (waves > 0) {
             // stamps of the last launch (every launch overwrites them)
@@ -142,12 +154,12 @@ int main(int argc, char** argv)
     };
 #define PAT(NL, MODE, BLOCK, label)                                                                         \
     run(label, (int)(N4 / (NL * 64)), [&](int b) {                                                          \
-        hipLaunchKernelGGL((k_pat<NL, MODE, BLOCK>), dim3((unsigned)(N4 / (NL * BLOCK))), dim3(BLOCK), 0, 0, \
+        hipLaunchKernelGGL((k_pat<NL, MODE, BLOCK>), dim3((unsigned)(N4 / (NL * BLOCK))), dim3(BLOCK), 0, cur, \
                            in[b], out, stamps);                                                             \
     });
-    run("stream U=1 grid 2048", 0, [&](int b) { hipLaunchKernelGGL(k_stream<1>, dim3(2048), dim3(256), 0, 0, in[b], N4, out); });
-    run("stream U=8 grid 2048", 0, [&](int b) { hipLaunchKernelGGL(k_stream<8>, dim3(2048), dim3(256), 0, 0, in[b], N4, out); });
-    run("stream U=4 grid 512", 0, [&](int b) { hipLaunchKernelGGL(k_stream<4>, dim3(512), dim3(256), 0, 0, in[b], N4, out); });
+    run("stream U=1 grid 2048", 0, [&](int b) { hipLaunchKernelGGL(k_stream<1>, dim3(2048), dim3(256), 0, cur, in[b], N4, out); });
+    run("stream U=8 grid 2048", 0, [&](int b) { hipLaunchKernelGGL(k_stream<8>, dim3(2048), dim3(256), 0, cur, in[b], N4, out); });
+    run("stream U=4 grid 512", 0, [&](int b) { hipLaunchKernelGGL(k_stream<4>, dim3(512), dim3(256), 0, cur, in[b], N4, out); });
     PAT(8, 0, 256, "contiguous 8 KiB/wave, 4096 waves, block 256")
     PAT(8, 1, 256, "4-lane pattern on tiles64, 4096 waves")
     PAT(8, 2, 256, "contiguous 8 KiB/wave, nt")
