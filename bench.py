@@ -562,6 +562,10 @@ def worker(args):
         }
         if not stub and serial_ms is not None:
             out["roofline"]["concurrent_launches"] = nb
+            out["roofline"]["note"] = ("independent steps overlap (%d launches in flight): achieved = bytes of the timed "
+                                       "region's launches / its device time; kernel_ms is that time per launch, not one "
+                                       "kernel's own duration, which one_at_a_time gives (rocprofv3 --kernel-trace "
+                                       "serialises concurrent kernels and shows that one)" % nb)
             out["roofline"]["one_at_a_time"] = {
                 "kernel_ms": serial_ms, "achieved": abytes / (serial_ms * 1e-3) / 1e9,
                 "frac": abytes / (serial_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
