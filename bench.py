@@ -240,6 +240,33 @@ def fp64_lines(device):
                      "achieved_GBps": ab / (ms * 1e-3) / 1e9, "frac": ab / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                      "one_at_a_time": {"kernel_ms": ms1, "frac": ab / (ms1 * 1e-3) / 1e9 / HBM_PEAK_GBPS}}
         del ring
+        # the bench workload itself in the reference's precision: C4 fp64, ring of 5 batches (358 MB)
+        A4, n4 = AGENTS, 5
+        w4 = scenarios.prepared(scenarios.config4(A=A4, nominal="uniform", seed=1234 + 4))
+        ty4 = torch.from_numpy(w4["obs_type"]).to(device)
+        flt4 = BatchedCBF(alpha=1.0, lr=1.45, lf=1.45, R=np.diag([0.5, 0.5]), streamed_obs=True)
+        ring4 = []
+        for b in range(n4):
+            sh = 64 * 131 * (b + 1)
+            ring4.append(dict(
+                state=torch.from_numpy(np.roll(w4["state"], sh, axis=0)).to(device),
+                u_ref=torch.from_numpy(np.roll(w4["u_ref"], sh, axis=0)).to(device),
+                obs=planes_to_tiled(torch.from_numpy(np.roll(w4["obs"], sh, axis=2)).to(device)),
+                u_out=torch.empty((A4, 2), dtype=torch.float64, device=device),
+                status=torch.empty((A4,), dtype=torch.int32, device=device)))
+
+        def launch4(b):
+            return lambda: flt4.solve(b["state"], b["u_ref"], b["obs"], ty4, u_out=b["u_out"], status=b["status"])
+        steps4 = [launch4(b) for b in ring4] * 2
+        ms1 = _time_graph(steps4, st, 2 * n4, 40)
+        ms = _time_graph(steps4, st, 2 * n4, 40, branches=3)
+        ab = algorithmic_bytes(A4, ROWS, w=8)
+        out["c4"] = {"workload": "C4 fp64: %d agents x %d rows (the bench workload in double precision)" % (A4, ROWS),
+                     "kernel_ms": ms, "launch": "hipGraph of %d launches in 3 parallel branches" % (2 * n4),
+                     "solves_per_s": A4 / (ms * 1e-3), "algorithmic_bytes_per_launch": ab,
+                     "achieved_GBps": ab / (ms * 1e-3) / 1e9, "frac": ab / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                     "one_at_a_time": {"kernel_ms": ms1, "frac": ab / (ms1 * 1e-3) / 1e9 / HBM_PEAK_GBPS}}
+        del ring4
         w = scenarios.radial_seekers(M=32)
         t = {k: torch.from_numpy(v).to(device) for k, v in w.items()}
         uo = torch.empty((1, 2), dtype=torch.float64, device=device)
