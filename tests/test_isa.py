@@ -3,7 +3,7 @@
 The kernel's overlap of loads and arithmetic rests on the compiler's counted `s_waitcnt vmcnt(N)`
 waits (loads issued in consumption order, every row waiting only for its own slots); a load in a
 conditional path, or another order of the loads, silently turns them into vmcnt(0).  Register and
-scratch use decide how many wavefronts fit on a SIMD.  One hipcc -S of the library, about a minute."""
+scratch use decide how many wavefronts fit on a SIMD."""
 import os
 import re
 import shutil
@@ -16,13 +16,33 @@ from sccav_cbf_amd import _build
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 
+KERNELS = """
+#include "sccbf_loop.hip.h"
+namespace {
+#define GROUP(T, G, RPL, NT) template __global__ void k_group<T, G, RPL, false, NT>( \\
+    long long, const T*, const T*, const T*, const unsigned char*, int, unsigned, const KArgs<T>);
+GROUP(float, 4, 4, false)
+GROUP(float, 4, 4, true)
+GROUP(float, 1, 16, false)
+GROUP(float, 16, 1, false)
+GROUP(double, 4, 4, false)
+template __global__ void k_nominal<float>(const NArgs<float>);
+}
+"""
+
+
 @pytest.fixture(scope="module")
 def asm(tmp_path_factory):
+    """The kernels under test, instantiated from the library's headers with the library's flags (the whole
+    library takes minutes to compile; these take seconds and come out the same)."""
     if not os.path.exists(HIPCC):
         pytest.skip("hipcc not available")
-    out = tmp_path_factory.mktemp("isa") / "sccbf.s"
+    d = tmp_path_factory.mktemp("isa")
+    src, out = d / "kernels.hip", d / "kernels.s"
+    src.write_text(KERNELS)
     flags = [f for f in _build.HIPCC_FLAGS if f not in ("-shared", "-fPIC")]
-    cmd = [HIPCC] + flags + ["--cuda-device-only", "-S", "-I" + os.path.dirname(_build.HDR), "-o", str(out), _build.SRC]
+    cmd = [HIPCC] + flags + ["--cuda-device-only", "-S", "-I" + os.path.dirname(_build.HDR), "-I" + _build.CSRC,
+                             "-o", str(out), str(src)]
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert res.returncode == 0, res.stdout[-2000:]
     return out.read_text()
@@ -40,9 +60,11 @@ def _meta(meta, key):
     return int(re.search(r"\.amdhsa_%s (\d+)" % key, meta).group(1))
 
 
-def test_bench_kernel_keeps_counted_waits_and_fits_seven_waves(asm):
-    # k_group<float, 4, 4, false, false>: 4 lanes per QP, 4 rows per lane: 2 + 4 * 3 = 14 loads per lane
-    body, meta = _kernel(asm, "_ZN12_GLOBAL__N_17k_groupIfLi4ELi4ELb0ELb0EEEv")
+@pytest.mark.parametrize("nt", ["Lb0", "Lb1"], ids=["cached", "non-temporal"])
+def test_bench_kernel_keeps_counted_waits_and_fits_seven_waves(asm, nt):
+    # k_group<float, 4, 4, false, NT>: 4 lanes per QP, 4 rows per lane: 2 + 4 * 3 = 14 loads per lane
+    # (the bench sets the streamed flag: the non-temporal instantiation is the one it runs)
+    body, meta = _kernel(asm, "_ZN12_GLOBAL__N_17k_groupIfLi4ELi4ELb0E%sEEEv" % nt)
     waits = [int(n) for n in re.findall(r"s_waitcnt vmcnt\((\d+)\)", body)]
     assert max(waits) >= 12, waits                    # the ego arithmetic starts with 12-13 loads still in flight
     assert len(set(waits)) >= 12, sorted(set(waits))  # and every later row waits for its own loads only
