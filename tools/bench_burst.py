@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""A short burst from an idle GPU: K = 20 steps of the bench workload between two synchronizations (the shape of
+`bench.py --steps 20`), by wall clock, median of 50 bursts: (a) one replay of a 20-launch graph, serial; (b) the same
+graph with three parallel branches; (c) three single-stream graphs of 7 + 7 + 6 launches started on three streams.
+python tools/bench_burst.py"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+from sccav_cbf_amd.batched import BatchedCBF, capture_independent  # noqa: E402
+
+
+def main():
+    dev = torch.device("cuda", 0)
+    K = 20
+    ring = bench.make_ring(0, dev, 10, layout="tiles", slots="prepared")
+    flt = BatchedCBF(alpha=1.0, lr=1.45, lf=1.45, R=np.diag([0.5, 0.5]), streamed_obs=True)
+    ty = ring[0]["obs_type"]
+
+    def step(i):
+        b = ring[i % len(ring)]
+        return lambda: flt.solve(b["state"], b["u_ref"], b["obs"], ty, u_out=b["u_out"], status=b["status"])
+    steps = [step(i) for i in range(K)]
+    for f in steps:
+        f()
+    torch.cuda.synchronize()
+    main_s = torch.cuda.Stream(dev)
+    side = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+    with torch.cuda.stream(main_s):
+        g1 = capture_independent(steps, 1)
+        g3 = capture_independent(steps, 3)
+    parts = []
+    for j, s in enumerate([main_s] + side):
+        with torch.cuda.stream(s):
+            parts.append((s, capture_independent(steps[j::3], 1)))
+
+    def burst_a():
+        with torch.cuda.stream(main_s):
+            g1.replay()
+
+    def burst_b():
+        with torch.cuda.stream(main_s):
+            g3.replay()
+
+    def burst_c():
+        for s, g in parts:
+            with torch.cuda.stream(s):
+                g.replay()
+
+    for name, fn in (("one serial graph", burst_a), ("one graph, three branches", burst_b),
+                     ("three graphs on three streams", burst_c)):
+        # keep the clocks up between the bursts, then idle the GPU as a synchronize does
+        ts = []
+        for rep in range(60):
+            for _ in range(30):
+                burst_a()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        ts = np.array(ts[10:]) * 1e6
+        print("%-32s %6.1f us per burst of %d steps (median; min %.1f) = %.2f us per step" %
+              (name, np.median(ts), K, ts.min(), np.median(ts) / K), flush=True)
+
+
+if __name__ == "__main__":
+    main()
