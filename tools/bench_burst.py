@@ -52,8 +52,40 @@ def main():
             with torch.cuda.stream(s):
                 g.replay()
 
-    for name, fn in (("one serial graph", burst_a), ("one graph, three branches", burst_b),
-                     ("three graphs on three streams", burst_c)):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    def burst_d():   # (b) between two timing events, as a profiled region has them
+        with torch.cuda.stream(main_s):
+            e0.record(main_s)
+            g3.replay()
+            e1.record(main_s)
+
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipEventCreateWithFlags.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint]
+    hip.hipEventRecord.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    hip.hipEventElapsedTime.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_void_p, ctypes.c_void_p]
+    made = {}
+    for label, flags in (("device-scope release", 0x40000000), ("no system fence", 0x20000000)):
+        h0, h1 = ctypes.c_void_p(), ctypes.c_void_p()
+        assert hip.hipEventCreateWithFlags(ctypes.byref(h0), flags) == 0
+        assert hip.hipEventCreateWithFlags(ctypes.byref(h1), flags) == 0
+        made[label] = (h0, h1)
+
+    def with_events(label):
+        h0, h1 = made[label]
+        sp = ctypes.c_void_p(main_s.cuda_stream)
+
+        def fn():
+            with torch.cuda.stream(main_s):
+                hip.hipEventRecord(h0, sp)
+                g3.replay()
+                hip.hipEventRecord(h1, sp)
+        return fn
+
+    for name, fn in (("one serial graph", burst_a), ("three branches + events, device-scope release", with_events("device-scope release")),
+                     ("three branches + events, no system fence", with_events("no system fence")), ("one graph, three branches", burst_b),
+                     ("three graphs on three streams", burst_c), ("three branches + two event records", burst_d)):
         # keep the clocks up between the bursts, then idle the GPU as a synchronize does
         ts = []
         for rep in range(60):
