@@ -429,8 +429,10 @@ def worker(args):
         t0 = time.perf_counter()
         for i in range(args.steps):
             step(i)
-        barrier()
+        sync()
         wall = time.perf_counter() - t0
+        barrier()
+        wall_barrier = time.perf_counter() - t0
         dev_ms = wall * 1e3
     else:
         stream = torch.cuda.Stream(device)
@@ -474,9 +476,12 @@ def worker(args):
             ev0.record(stream)
             run(args.steps)
             ev1.record(stream)
+            # every rank stops its own clock when its own K steps are done (the maximum over the ranks is the
+            # job's time); the closing barrier follows, and the time up to its end is reported beside it
+            sync()
+            wall = time.perf_counter() - t0
             barrier()
-            t1 = time.perf_counter()
-            wall = t1 - t0
+            wall_barrier = time.perf_counter() - t0
             dev_ms = ev0.elapsed_time(ev1)
             # the same steps one at a time (a serial graph), outside the timed region: what a caller whose
             # launches depend on each other gets, and what a per-kernel profile shows; and the proof that the
@@ -521,9 +526,11 @@ def worker(args):
     rank_ms = [wall / args.steps * 1e3]
     coll_ranks = 1
     if dist is not None:
-        tw = torch.tensor([wall], dtype=torch.float64, device=device)
-        allw = torch.empty((world,), dtype=torch.float64, device=device)
+        tw = torch.tensor([wall, wall_barrier], dtype=torch.float64, device=device)
+        allw = torch.empty((2 * world,), dtype=torch.float64, device=device)
         dist.all_gather_into_tensor(allw, tw)
+        allw, allb = allw.view(world, 2)[:, 0].contiguous(), allw.view(world, 2)[:, 1]
+        wall_barrier = float(allb.max().item())
         one = torch.ones((1,), dtype=torch.int32, device=device)
         dist.all_reduce(one, op=dist.ReduceOp.SUM)
         sync()
@@ -609,6 +616,8 @@ def worker(args):
         if dist is not None:
             out["rccl_ranks" if not stub else "gloo_ranks"] = coll_ranks
             out["ms_per_step_by_rank"] = rank_ms
+            # the clock of ms_per_step stops when the rank's own steps are done; this one after the closing barrier
+            out["ms_per_step_to_end_of_closing_barrier"] = wall_barrier / args.steps * 1e3
             out["gather_ms_per_step"] = gather_ms   # not part of value / ms_per_step
             if coll_ranks != world:
                 print("bench.py: the collective saw %d ranks, expected %d" % (coll_ranks, world), file=sys.stderr)
