@@ -83,22 +83,34 @@ def main():
                 hip.hipEventRecord(h1, sp)
         return fn
 
-    for name, fn in (("one serial graph", burst_a), ("three branches + events, device-scope release", with_events("device-scope release")),
-                     ("three branches + events, no system fence", with_events("no system fence")), ("one graph, three branches", burst_b),
-                     ("three graphs on three streams", burst_c), ("three branches + two event records", burst_d)):
+    def branches(nb):
+        with torch.cuda.stream(main_s):
+            g = capture_independent(steps, nb)
+
+        def fn():
+            with torch.cuda.stream(main_s):
+                g.replay()
+        return fn
+
+    cases = [("one serial graph", burst_a), ("three branches + events, device-scope release", with_events("device-scope release")),
+             ("three branches + events, no system fence", with_events("no system fence")), ("one graph, three branches", burst_b),
+             ("three graphs on three streams", burst_c), ("three branches + two event records", burst_d)]
+    cases += [("one graph, %d branches" % nb, branches(nb)) for nb in (2, 4, 5, 7, 10)]
+    for name, fn in cases:
         # keep the clocks up between the bursts, then idle the GPU as a synchronize does
-        ts = []
+        ts, th = [], []
         for rep in range(60):
             for _ in range(30):
                 burst_a()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             fn()
+            th.append(time.perf_counter() - t0)
             torch.cuda.synchronize()
             ts.append(time.perf_counter() - t0)
-        ts = np.array(ts[10:]) * 1e6
-        print("%-32s %6.1f us per burst of %d steps (median; min %.1f) = %.2f us per step" %
-              (name, np.median(ts), K, ts.min(), np.median(ts) / K), flush=True)
+        ts, th = np.array(ts[10:]) * 1e6, np.array(th[10:]) * 1e6
+        print("%-46s %6.1f us per burst of %d steps (median; min %.1f) = %.2f us per step; the host call returns after %.1f us" %
+              (name, np.median(ts), K, ts.min(), np.median(ts) / K, np.median(th)), flush=True)
 
 
 if __name__ == "__main__":
