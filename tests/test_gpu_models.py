@@ -179,10 +179,12 @@ def test_closed_loop_ticks_with_the_steer_rate_filter(oracle):
 
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
 @pytest.mark.parametrize("dyn", ["dum", "sadbm"])
-@pytest.mark.parametrize("M,lanes", [(300, 0), (24, 64), (1024, 64), (24, 32), (300, 16), (700, 0), (1024, 0)])
+@pytest.mark.parametrize("M,lanes", [(300, 0), (24, 64), (1024, 64), (24, 32), (300, 16), (700, 0), (1024, 0),
+                                     (40, 4), (48, 8), (72, 8), (96, 16), (80, 16), (100, 0)])
 def test_one_wavefront_per_qp_for_the_other_models(oracle, dyn, M, lanes, dtype):
     """More rows than sixteen lanes hold (and the same kernel forced on a short list): 16 or 32 lanes or one
-    wavefront per QP, rows in LDS only, for the unicycle-input and the steer-rate model."""
+    wavefront per QP, rows in LDS only, for the unicycle-input and the steer-rate model; and row counts that
+    leave whole register rows of the 4-, 8- and 16-lane kernels unused (their arithmetic is skipped)."""
     A, dt = 96, 0.05
     base = scenarios.config4(A=A, nominal="uniform", seed=5)
     reps = -(-M // 16)
@@ -216,5 +218,5 @@ def test_one_wavefront_per_qp_for_the_other_models(oracle, dyn, M, lanes, dtype)
     scale = np.maximum(1.0, np.hypot(uo[:, 0], uo[:, 1]))
     assert (np.abs(ug - uo).max(axis=1) / scale)[both].max(initial=0) <= (1e-8 if dtype == torch.float64 else 5e-3)
     if dyn == "sadbm":
-        ok = sg == so
+        ok = (sg == so) & ((so != 0) | both)     # the slip follows the input: the agents whose inputs are compared
         assert np.abs(sl.double().cpu().numpy() - so_slip)[ok].max() <= (1e-9 if dtype == torch.float64 else 1e-4)

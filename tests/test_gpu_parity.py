@@ -367,6 +367,31 @@ def test_rows_in_lds_only_up_to_the_maximum_row_count(oracle, M, lanes, dtype):
         _check(ug, sg, uo, so, ro, w["u_ref"], dtype)
 
 
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("M,lanes", [(9, 1), (12, 1), (20, 2), (40, 4), (48, 4), (33, 4), (40, 8), (48, 8), (72, 8),
+                                     (96, 8), (100, 8), (65, 16), (80, 16), (96, 16), (112, 16), (48, 0), (96, 0)])
+def test_row_counts_that_leave_register_rows_unused(oracle, M, lanes, dtype):
+    """Rows in registers, 8 or 16 per lane, of which the last ones lie past M for every lane of a group: those
+    are empty rows whose arithmetic and scan are skipped.  Answers and rows against the oracle, and the QP stage
+    alone on the same rows."""
+    A = 333
+    w = _many_rows(A, M, 500 + M)
+    uo, so, ro = _orc_solve(oracle, w)
+    ug, sg, rg = _gpu_solve(w, dtype, lanes)
+    _check(ug, sg, uo, so, ro, w["u_ref"], dtype)
+    tol = 1e-9 if dtype == torch.float64 else 1e-3
+    assert (np.abs(rg - ro) / (np.abs(ro).max(axis=2, keepdims=True) + 1.0)).max() <= tol
+    if dtype == torch.float64:
+        dev = _dev()
+        f = _filter(lanes=lanes, slip_io=True)
+        rows = np.ascontiguousarray(ro)
+        uq, sq = f.solve_qp(torch.from_numpy(rows).to(dev), torch.from_numpy(w["u_ref"]).to(dev))
+        torch.cuda.synchronize()
+        uqo, sqo = oracle.qp_batch(oracle.make_params(R=R_HALF.reshape(-1)), rows, w["u_ref"])
+        assert (sq.cpu().numpy() == sqo).all()
+        assert np.abs(uq.cpu().numpy() - uqo).max() <= 1e-8 * (1 + np.abs(uqo).max())
+
+
 def test_beyond_the_maximum_row_count_is_refused():
     M = _lib.MAX_ROWS
     w = scenarios.monte_carlo(3, M // 2, M // 2, 77, nominal="uniform")
