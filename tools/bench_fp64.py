@@ -18,6 +18,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--lanes", default="0,2,4,8,16")
     ap.add_argument("--agents", type=int, default=65536)
+    ap.add_argument("--eager", type=int, default=0, help="only this many eager launches per lanes value (for counter runs)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     A, n = args.agents, 5
@@ -40,6 +41,11 @@ def main():
             def launch(b):
                 return lambda: f.solve(b["state"], b["u_ref"], b["obs"], ty, u_out=b["u_out"], status=b["status"])
             steps = [launch(b) for b in ring] * 2
+            if args.eager:
+                for i in range(args.eager):
+                    steps[i % len(steps)]()
+                torch.cuda.synchronize()
+                continue
             ms1 = bench._time_graph(steps, st, 2 * n, 30)
             ms3 = bench._time_graph(steps, st, 2 * n, 30, branches=3)
             print("fp64 lanes %2d: one at a time %.2f us (%.3f of 8 TB/s), three in flight %.2f us (%.3f)" %

@@ -130,6 +130,28 @@ __global__ __launch_bounds__(256) void k_rowsonly(const KArgs<float> p)
     if (g == 0) store_result_(p, qp, false, 0, acc, acc, e, ur0, ur1);
 }
 
+// K3: the library's k_group<float, G, RPL> with some workgroups holding their loads back: do a launch's load
+// and arithmetic phases overlap better when half of a CU's wavefronts start later?
+// MODE picks the late workgroups by index: 1: (i >> 8) & 1, 2: (i >> 9) & 1, 3: i & 1, 4: (i >> 3) & 1, 5: (i >> 7) & 1
+template <int G, int RPL, int MODE>
+__global__ __launch_bounds__(kBlock) void k_group_late(long long A, const float* obs, const float* state, const float* u_ref,
+                                                       const uint8_t* obs_type, int M, unsigned flags,
+                                                       const KArgs<float> rest, int naps)
+{
+    KArgs<float> p = rest;
+    p.A = A; p.obs = obs; p.state = state; p.u_ref = u_ref; p.obs_type = obs_type; p.M = M; p.flags = flags;
+    const int g = (int)(threadIdx.x % G);
+    const long long qp = (long long)blockIdx.x * (kBlock / G) + threadIdx.x / G;
+    if (qp >= p.A) return;
+    const unsigned i = blockIdx.x;
+    const bool late = MODE == 1 ? (i >> 8) & 1 : MODE == 2 ? (i >> 9) & 1 : MODE == 3 ? i & 1 : MODE == 4 ? (i >> 3) & 1 : (i >> 7) & 1;
+    if (late)
+        for (int n = 0; n < naps; ++n) __builtin_amdgcn_s_sleep(8);   // 8 x 64 cycles
+    LaneLoads<float, RPL> L;
+    group_load_<float, RPL, false, true>(p, qp, g, G, L);
+    group_solve_<float, G, RPL, false>(p, qp, g, L);
+}
+
 struct Batch {
     float *state, *u_ref, *obs, *u_out;
     uint8_t* type;
@@ -242,6 +264,16 @@ int main(int argc, char** argv)
     if (!quick) { RUN_G(1, 16) RUN_G(2, 8) }
     RUN_G(4, 4)
     if (!quick) { RUN_G(8, 2) RUN_G(16, 1) }
+    if (argc > 6) {  // late workgroups: naps of 512 cycles
+#define RUN_LATE(MODE) \
+        for (int naps : {0, 2, 4, 6, 8, 12}) { \
+            char nm[64]; \
+            snprintf(nm, sizeof nm, "late mode " #MODE " naps %d", naps); \
+            report(nm, time_it([&](int b) { setk(b); hipLaunchKernelGGL((k_group_late<4, 4, MODE>), dim3((unsigned)((A * 4 + 255) / 256)), dim3(256), 0, 0, \
+                k.A, k.obs, k.state, k.u_ref, k.obs_type, k.M, k.flags, k, naps); }, ITERS, RING)); \
+        }
+        RUN_LATE(1) RUN_LATE(2) RUN_LATE(3) RUN_LATE(4) RUN_LATE(5)
+    }
     CK(hipDeviceSynchronize());
     int st[8];
     CK(hipMemcpy(st, ring[0].status, sizeof st, hipMemcpyDeviceToHost));
