@@ -200,14 +200,8 @@ __device__ inline void group_solve_(const KArgs<T>& p, long long qp, int g, cons
 // The arguments every wave needs before it can issue its first loads come first and one
 // by one: the leading 16 dwords of the kernel arguments are preloaded into SGPRs at wave
 // launch (-amdgpu-kernarg-preload-count), which a by-value struct does not qualify for.
-// Wavefronts per SIMD the compiler has to leave room for: the fp64 kernel with up to four rows per lane needs 130
-// registers when left alone, two more than four wavefronts per SIMD allow, and a launch of 65536 QPs x 4 lanes is
-// exactly four wavefronts per SIMD: with three, a quarter of them wait for a second round.
-template <typename T, int RPL> constexpr int group_min_waves() { return (sizeof(T) == 8 && RPL <= 4) ? 4 : 1; }
-
 template <typename T, int G, int RPL, bool QP_ONLY, bool NT>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(group_min_waves<T, RPL>())))
-void k_group(long long A, const T* obs, const T* state, const T* u_ref,
+__global__ __launch_bounds__(kBlock) void k_group(long long A, const T* obs, const T* state, const T* u_ref,
                                                   const uint8_t* obs_type, int M, unsigned flags,
                                                   const KArgs<T> rest)
 {
