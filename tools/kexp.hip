@@ -3,6 +3,8 @@
 // Includes the library source to reuse its device code; kernels here ablate stages.
 #include "../sccav_cbf_amd/csrc/sccbf.hip"
 
+#include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <random>
@@ -273,6 +275,37 @@ int main(int argc, char** argv)
                 k.A, k.obs, k.state, k.u_ref, k.obs_type, k.M, k.flags, k, naps); }, ITERS, RING)); \
         }
         RUN_LATE(1) RUN_LATE(2) RUN_LATE(3) RUN_LATE(4) RUN_LATE(5)
+    }
+    if (argc > 6) {  // a burst of 20 launches from an idle GPU, dealt eagerly to n streams forked from / joined to stream 0
+        for (int ns : {1, 2, 3, 4}) {
+            hipStream_t st[4];
+            hipEvent_t ev[4];
+            for (int j = 0; j < ns; ++j) { CK(hipStreamCreate(&st[j])); CK(hipEventCreateWithFlags(&ev[j], hipEventDisableTiming)); }
+            std::vector<double> wall, host;
+            for (int rep = 0; rep < 60; ++rep) {
+                for (int i = 0; i < 30; ++i) { setk(i % RING); launch_group<float, false, 4, 4>(k, st[0]); }  // clocks up
+                CK(hipDeviceSynchronize());
+                const auto t0 = std::chrono::steady_clock::now();
+                if (ns > 1) {
+                    CK(hipEventRecord(ev[0], st[0]));
+                    for (int j = 1; j < ns; ++j) CK(hipStreamWaitEvent(st[j], ev[0], 0));
+                }
+                for (int i = 0; i < 20; ++i) { setk(i % RING); launch_group<float, false, 4, 4>(k, st[i % ns]); }
+                for (int j = 1; j < ns; ++j) { CK(hipEventRecord(ev[j], st[j])); CK(hipStreamWaitEvent(st[0], ev[j], 0)); }
+                const auto t1 = std::chrono::steady_clock::now();
+                CK(hipStreamSynchronize(st[0]));
+                const auto t2 = std::chrono::steady_clock::now();
+                if (rep >= 10) {
+                    host.push_back(std::chrono::duration<double, std::micro>(t1 - t0).count());
+                    wall.push_back(std::chrono::duration<double, std::micro>(t2 - t0).count());
+                }
+            }
+            std::sort(wall.begin(), wall.end());
+            std::sort(host.begin(), host.end());
+            printf("burst of 20 eager launches on %d stream(s): %.1f us to the end of the synchronize (median; min %.1f), host calls %.1f us\n",
+                   ns, wall[wall.size() / 2], wall[0], host[host.size() / 2]);
+            fflush(stdout);
+        }
     }
     CK(hipDeviceSynchronize());
     int st[8];
