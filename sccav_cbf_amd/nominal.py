@@ -117,8 +117,10 @@ def vehicle_step_kin(state, u, mode, L=2.9, max_steer=np.radians(30.0), dt=0.1):
 class ClosedLoop:
     """nominal -> filter -> vehicle step for a batch, every tensor resident on the GPU.
 
-    tick() launches three kernels on the current stream and allocates nothing, so a caller may
-    capture a number of ticks in a hipGraph.  Obstacles are whatever `obs` holds when the tick
+    tick() launches two or three kernels on the current stream and, for the "dbm" and "sadbm" models,
+    allocates nothing, so a caller may capture a number of ticks in a hipGraph ("kbm" and "dum" convert
+    the nominal input with torch element-wise ops, whose temporaries come from torch's allocator: capturable
+    too, through torch's graph pool).  Obstacles are whatever `obs` holds when the tick
     runs: move them between ticks (or inside the captured region) with ordinary tensor ops.
 
     nominal=None, traj=None: no course, the nominal input is (0, 0) on every tick (the stationary
