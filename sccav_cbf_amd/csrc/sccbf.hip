@@ -27,6 +27,8 @@
 // (nominal controller, vehicle step, rollout), sccbf_ext.hip.h (unicycle-input and steer-rate
 // models), sccbf_ingest.hip.h (bounding boxes and lane points -> slots); this file: host-side
 // dispatch and the C ABI.
+#include <atomic>
+
 #include "sccbf_loop.hip.h"
 #include "sccbf_ext.hip.h"
 #include "sccbf_ingest.hip.h"
@@ -167,14 +169,16 @@ template <auto Kernel> bool grant_lds(size_t lds)
 {
     if (lds <= 64 * 1024) return true;
     if (lds > kLdsPerCu) return false;
-    static bool done[64] = {};
+    // the only state the library keeps: which devices have the attribute (setting it twice from two
+    // threads at once is harmless, the flag only saves the call)
+    static std::atomic<bool> done[64];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
-    if (!done[dev]) {
+    if (!done[dev].load(std::memory_order_acquire)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(Kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)kLdsPerCu) != hipSuccess)
             return false;
-        done[dev] = true;
+        done[dev].store(true, std::memory_order_release);
     }
     return true;
 }
@@ -435,7 +439,8 @@ template <typename T>
 int vehicle_step_impl(int64_t A, T* state, const T* u, double lr, double lf, double max_steer, double dt,
                       T* beta_out, void* stream)
 {
-    if (A < 0 || A > 0x7fffffffLL || !(lr > 0.0) || !(lf + lr > 0.0) || !(max_steer >= 0.0)) return SCCBF_ERR_ARG;
+    if (A < 0 || A > 0x7fffffffLL || !(lr > 0.0) || !(lf + lr > 0.0) || !(max_steer >= 0.0) || !std::isfinite(dt))
+        return SCCBF_ERR_ARG;
     if (A == 0) return SCCBF_OK;
     if (!state || !u) return SCCBF_ERR_ARG;
     const long long blocks = (A + kBlock - 1) / kBlock;
