@@ -15,7 +15,8 @@
  *     stream); the caller synchronises
  *   - return value 0 = launched, <0 = argument / launch error
  *     (sccbf_strerror); no exception crosses the ABI
- *   - no global state: calls are re-entrant and thread-safe
+ *   - calls are re-entrant and thread-safe; the only state the library keeps is one flag per device that
+ *     says a one-time kernel attribute (more than 64 KB of LDS for long row lists) has been set
  *
  * Memory layout ("T" = float for *_f32, double for *_f64; A agents, M slots)
  *   state    T[A][4]        x, y, theta(yaw), v         one 4-vector / agent
