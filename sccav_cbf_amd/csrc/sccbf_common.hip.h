@@ -73,14 +73,16 @@ template <typename T> struct KArgs {
 };
 
 // ------------------------------------------------------------------ math shims
-// fp32: the hardware sin/cos unit (argument in revolutions, reduced to [0, 1) so that any
-// magnitude is in its range; the angle error is |x| 2^-24, 2e-7 rad for a heading in
-// [-pi, pi]); 1-ulp rcp / sqrt / rsq instead of the IEEE division and denormal-safe sqrt
-// sequences.  Library sincosf/tanf would pull a Payne-Hanek reduction with a scratch
+// fp32: the hardware sin/cos unit (argument in revolutions, reduced to [-1/2, 1/2] so that any
+// magnitude is in its range and a small angle of either sign keeps its relative accuracy: reduced
+// to [0, 1) instead, a heading just below zero would sit next to 1 and lose it, 14 % of its sine
+// at -1e-6 rad; the angle error is |x| 2^-24, 2e-7 rad for a heading in [-pi, pi]); 1-ulp rcp /
+// sqrt / rsq instead of the IEEE division and denormal-safe sqrt sequences.  Library sincosf/tanf would pull a Payne-Hanek reduction with a scratch
 // table into every call site.  fp64 keeps the full-accuracy library forms.
 __device__ inline void sincos_(float x, float* s, float* c)
 {
-    const float r = __builtin_amdgcn_fractf(x * 0.15915494309189535f);
+    const float t = x * 0.15915494309189535f;
+    const float r = t - __builtin_rintf(t);
     *s = __builtin_amdgcn_sinf(r);
     *c = __builtin_amdgcn_cosf(r);
 }
