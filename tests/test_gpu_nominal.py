@@ -111,6 +111,26 @@ def test_vehicle_step_matches_oracle(oracle, dtype):
     assert np.abs(bo).max() <= np.arctan(0.5 * np.tan(np.radians(30.0))) + 1e-12
 
 
+def test_small_headings_of_either_sign_keep_their_sine():
+    """fp32 sine of a heading within 0.1 rad of zero, above and below: relative accuracy, read back from a vehicle
+    step from the origin with unit speed, unit time step and no input (y' = sin(yaw)).  Reduced to [0, 1)
+    revolutions a negative heading sat next to 1 and its sine was off by up to 14 %; a cone at the agent's own
+    velocity amplifies that into its row."""
+    from sccav_cbf_amd.nominal import vehicle_step
+    th = 10.0 ** np.linspace(-6, -1, 2000)
+    th = np.concatenate([th, -th]).astype(np.float32)
+    A = th.shape[0]
+    state = np.zeros((A, 4), dtype=np.float32)
+    state[:, 2], state[:, 3] = th, 1.0
+    ts = torch.from_numpy(state).to(DEV)
+    vehicle_step(ts, torch.zeros((A, 2), dtype=torch.float32, device=DEV), 1.45, 1.45, np.radians(30.0), 1.0)
+    torch.cuda.synchronize()
+    got = ts.double().cpu().numpy()
+    want = np.sin(th.astype(np.float64))
+    assert np.abs(got[:, 1] / want - 1.0).max() <= 3e-6
+    assert np.abs(got[:, 0] - np.cos(th.astype(np.float64))).max() <= 3e-7
+
+
 def test_c1_closed_loop_entirely_on_the_gpu():
     """The as-shipped scenario of stanley_controller_ellipse.py (Stanley + P, one collision-cone row,
     DBM filter, update_com) with nominal, filter and vehicle step all on the device, fp64: the slip-angle
