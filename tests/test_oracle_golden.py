@@ -47,3 +47,27 @@ def test_replay_with_true_ellipse_row_stays_outside():
     h = [((s[0] - k["o_cx"]) / 20.0) ** 2 + ((s[1] - k["o_cy"]) / 10.0) ** 2 - 1 for (s, *_r) in log]
     assert min(h) > -1e-6
     assert len(t) > 100
+
+
+def test_oracle_reproduces_its_frozen_vectors():
+    """tests/golden/oracle_cases.npz (written by make_oracle_fixtures.py from this oracle): barrier values and
+    partials of every obstacle kind with their degenerate cases, the filter of every vehicle model on two batches,
+    hand-made and random QPs.  The oracle of today must give the same numbers: the GPU parity tests are measured
+    against it."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_oracle_fixtures", os.path.join(GOLDEN, "make_oracle_fixtures.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    now = mod.build()
+    g = np.load(os.path.join(GOLDEN, "oracle_cases.npz"))
+    assert sorted(now) == sorted(g.files)
+    for name in g.files:
+        a, b = np.asarray(now[name]), g[name]
+        assert a.shape == b.shape and a.dtype == b.dtype, name
+        if a.dtype.kind == "f":
+            assert np.allclose(a, b, rtol=1e-11, atol=1e-12, equal_nan=True), name
+        else:
+            assert np.array_equal(a, b), name
+    # the degenerate cases are in the file and finite
+    assert np.isfinite(g["bar_out"]).all() and len(g["bar_kind"]) >= 200
+    assert (g["qp_hand_status"] == 1).sum() == 3 and (g["qp_rand_status"] == 1).sum() > 60
