@@ -67,6 +67,13 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # One HIP runtime per process, and it has to be the one the tensors come from: PyTorch ships its own copy, so
+    # torch is imported before the library is mapped.  Mapped first, libsccbf.so would pull in the system's
+    # runtime, torch would then bring its own, and the library's kernels would fail to launch on torch's streams.
+    try:
+        import torch  # noqa: F401
+    except ImportError:   # a caller without PyTorch (ctypes on its own hipMalloc memory): the system's runtime
+        pass
     alt = os.environ.get("SCCBF_LIBRARY")   # another build of the same sources (measurements of build options)
     if alt:
         return _bind(C.CDLL(alt))

@@ -1,7 +1,8 @@
 """Single-ego bridge from the object API to the C ABI (fp64, one agent per call).
 
-The per-call cost is a few small host<->device copies; batches of agents should use
-sccav_cbf_amd.BatchedCBF directly.  There is no CPU path: without a GPU these raise.
+One call = one copy in, one launch, one copy out: inputs and outputs of a list of M obstacles live in one
+device buffer that is kept per (device, M).  Batches of agents should use sccav_cbf_amd.BatchedCBF
+directly.  There is no CPU path: without a GPU these raise.  Like the reference's objects, not re-entrant.
 """
 import ctypes as C
 
@@ -17,10 +18,61 @@ def _torch():
     return torch
 
 
-def _pack(slots):
-    """(M, 8) -> ABI layout (M, 2, 1, 4) for a single agent."""
-    M = slots.shape[0]
-    return np.ascontiguousarray(slots.reshape(M, 2, 1, 4))
+def _r4(n):
+    return (n + 3) // 4 * 4
+
+
+class _Bridge:
+    """Device buffer of one ego with M obstacle slots, in doubles, every part on a 32-byte boundary:
+       state 4 | u_ref 2 | obs 8 M (the ABI's (M, 2, 1, 4)) | kinds M bytes | slip 2 | u 2 | status (int32) | out 8 M
+    Everything up to and including slip is uploaded in one copy, everything from slip on comes back in one."""
+
+    def __init__(self, torch, dev, M):
+        self.torch, self.M = torch, M
+        self.o_state, self.o_uref, self.o_obs = 0, 4, 8
+        self.o_kind = 8 + 8 * M
+        self.o_slip = self.o_kind + _r4((M + 7) // 8)
+        self.o_u = self.o_slip + 4
+        self.o_status = self.o_u + 4
+        self.o_out = self.o_status + 4
+        self.buf = torch.zeros(self.o_out + 8 * M, dtype=torch.float64, device=dev)
+        self.host = np.zeros(self.o_u)
+        self.kinds = self.host[self.o_kind:self.o_slip].view(np.uint8)
+
+    def ptr(self, off):
+        return C.c_void_p(self.buf.data_ptr() + 8 * off)
+
+    def upload(self, s, kinds, slots, u_ref=None, slip=None):
+        h, M = self.host, self.M
+        h[0:4] = np.asarray(s, dtype=np.float64).reshape(4)
+        h[4:6] = 0.0 if u_ref is None else np.asarray(u_ref, dtype=np.float64).reshape(2)
+        h[8:8 + 8 * M] = np.asarray(slots, dtype=np.float64).reshape(-1)
+        self.kinds[:M] = kinds
+        h[self.o_slip:self.o_slip + 2] = 0.0 if slip is None else np.asarray(slip, dtype=np.float64).reshape(2)
+        self.buf[:self.o_u].copy_(self.torch.from_numpy(h))
+
+    def download(self):
+        """slip (2), u (2), status, out (8 M doubles: rows (M, 4) first, or partials (M, 2, 1, 4))."""
+        d = self.buf[self.o_slip:].cpu().numpy()
+        return d[0:2], d[4:6], int(d[8:9].view(np.int32)[0]), d[12:]
+
+
+_bridges = {}
+
+
+def _bridge(M):
+    torch = _torch()
+    key = (torch.cuda.current_device(), M)
+    b = _bridges.get(key)
+    if b is None:
+        if len(_bridges) > 64:      # lists of many different lengths: keep the table small
+            _bridges.clear()
+        b = _bridges[key] = _Bridge(torch, torch.device("cuda", key[0]), M)
+    return b
+
+
+def _stream(torch):
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
 _last_partials = (None, None)   # (key, result) of the latest partials() call
@@ -40,68 +92,43 @@ def partials(s, kinds, slots, zero_tol=1e-3):
     key = (s.tobytes(), kinds.tobytes(), slots.tobytes(), float(zero_tol))
     if _last_partials[0] == key:
         return _last_partials[1].copy()
-    torch = _torch()
     lib = _lib.load()
-    dev = torch.device("cuda", torch.cuda.current_device())
-    st = torch.tensor(np.asarray(s, dtype=np.float64).reshape(1, 4), device=dev)
-    ob = torch.tensor(_pack(np.asarray(slots, dtype=np.float64)), device=dev)
-    ty = torch.tensor(kinds, device=dev)
-    out = torch.empty((M, 2, 1, 4), dtype=torch.float64, device=dev)
+    b = _bridge(M)
+    b.upload(s, kinds, slots)
     p = _lib.Params()
     lib.sccbf_default_params(C.byref(p))
     p.zero_tol = zero_tol
-    stream = torch.cuda.current_stream(dev).cuda_stream
-    _lib.check(lib.sccbf_partials_f64(C.byref(p), 1, M, C.c_void_p(st.data_ptr()),
-                                      C.c_void_p(ob.data_ptr()), C.c_void_p(ty.data_ptr()),
-                                      C.c_void_p(out.data_ptr()), C.c_void_p(stream)))
-    o = out.cpu().numpy().reshape(M, 8)[:, :6].copy()
+    _lib.check(lib.sccbf_partials_f64(C.byref(p), 1, M, b.ptr(b.o_state), b.ptr(b.o_obs), b.ptr(b.o_kind),
+                                      b.ptr(b.o_out), _stream(b.torch)))
+    o = b.download()[3].reshape(M, 8)[:, :6].copy()
     _last_partials = (key, o)
     return o.copy()
 
 
 def solve(params, s, u_ref, kinds, slots):
     """One QP for one ego: returns (u (2,), status, rows (M,4))."""
-    torch = _torch()
     lib = _lib.load()
     kinds = np.ascontiguousarray(kinds, dtype=np.uint8)
     M = kinds.shape[0]
-    dev = torch.device("cuda", torch.cuda.current_device())
-    st = torch.tensor(np.asarray(s, dtype=np.float64).reshape(1, 4), device=dev)
-    ur = torch.tensor(np.asarray(u_ref, dtype=np.float64).reshape(1, 2), device=dev)
-    ob = torch.tensor(_pack(np.asarray(slots, dtype=np.float64)), device=dev)
-    ty = torch.tensor(kinds, device=dev)
-    u = torch.empty((1, 2), dtype=torch.float64, device=dev)
-    status = torch.empty((1,), dtype=torch.int32, device=dev)
-    rows = torch.empty((M, 1, 4), dtype=torch.float64, device=dev)
-    stream = torch.cuda.current_stream(dev).cuda_stream
-    _lib.check(lib.sccbf_solve_f64(C.byref(params), 1, M, C.c_void_p(st.data_ptr()),
-                                   C.c_void_p(ur.data_ptr()), C.c_void_p(ob.data_ptr()),
-                                   C.c_void_p(ty.data_ptr()), C.c_void_p(u.data_ptr()),
-                                   C.c_void_p(status.data_ptr()), C.c_void_p(rows.data_ptr()),
-                                   C.c_void_p(stream)))
-    return u.cpu().numpy()[0], int(status.item()), rows.cpu().numpy()[:, 0, :]
+    b = _bridge(M)
+    b.upload(s, kinds, slots, u_ref=u_ref)
+    _lib.check(lib.sccbf_solve_f64(C.byref(params), 1, M, b.ptr(b.o_state), b.ptr(b.o_uref), b.ptr(b.o_obs),
+                                   b.ptr(b.o_kind), b.ptr(b.o_u), b.ptr(b.o_status), b.ptr(b.o_out),
+                                   _stream(b.torch)))
+    _, u, status, out = b.download()
+    return u.copy(), status, out[:4 * M].reshape(M, 4).copy()
 
 
 def solve_sa(params, dt, s, slip, u_ref, kinds, slots):
     """One steer-rate QP for one ego (sccbf_solve_sa_f64): returns (u (2,), status, rows (M,4),
     slip (2,) = beta, beta_ref_last after the call)."""
-    torch = _torch()
     lib = _lib.load()
     kinds = np.ascontiguousarray(kinds, dtype=np.uint8)
     M = kinds.shape[0]
-    dev = torch.device("cuda", torch.cuda.current_device())
-    st = torch.tensor(np.asarray(s, dtype=np.float64).reshape(1, 4), device=dev)
-    sl = torch.tensor(np.asarray(slip, dtype=np.float64).reshape(1, 2), device=dev)
-    ur = torch.tensor(np.asarray(u_ref, dtype=np.float64).reshape(1, 2), device=dev)
-    ob = torch.tensor(_pack(np.asarray(slots, dtype=np.float64)), device=dev)
-    ty = torch.tensor(kinds, device=dev)
-    u = torch.empty((1, 2), dtype=torch.float64, device=dev)
-    status = torch.empty((1,), dtype=torch.int32, device=dev)
-    rows = torch.empty((M, 1, 4), dtype=torch.float64, device=dev)
-    stream = torch.cuda.current_stream(dev).cuda_stream
-    _lib.check(lib.sccbf_solve_sa_f64(C.byref(params), float(dt), 1, M, C.c_void_p(st.data_ptr()),
-                                      C.c_void_p(sl.data_ptr()), C.c_void_p(ur.data_ptr()),
-                                      C.c_void_p(ob.data_ptr()), C.c_void_p(ty.data_ptr()),
-                                      C.c_void_p(u.data_ptr()), C.c_void_p(status.data_ptr()),
-                                      C.c_void_p(rows.data_ptr()), C.c_void_p(stream)))
-    return u.cpu().numpy()[0], int(status.item()), rows.cpu().numpy()[:, 0, :], sl.cpu().numpy()[0]
+    b = _bridge(M)
+    b.upload(s, kinds, slots, u_ref=u_ref, slip=slip)
+    _lib.check(lib.sccbf_solve_sa_f64(C.byref(params), float(dt), 1, M, b.ptr(b.o_state), b.ptr(b.o_slip),
+                                      b.ptr(b.o_uref), b.ptr(b.o_obs), b.ptr(b.o_kind), b.ptr(b.o_u),
+                                      b.ptr(b.o_status), b.ptr(b.o_out), _stream(b.torch)))
+    sl, u, status, out = b.download()
+    return u.copy(), status, out[:4 * M].reshape(M, 4).copy(), sl.copy()

@@ -59,6 +59,11 @@
 namespace {
 
 // ------------------------------------------------------------------- host side
+// hipGetLastError() reports the last error of ANY earlier runtime call of the calling thread (another library's
+// failed probe, say) until somebody reads it.  Every entry point reads it away first, so that what it reads after
+// its launch is its own launch's.
+inline void forget_earlier_errors_() { (void)hipGetLastError(); }
+
 template <typename T>
 int fill_args(const sccbf_params* sp, int64_t A, int32_t M, KArgs<T>& k)
 {
@@ -300,6 +305,7 @@ int solve_impl(const sccbf_params* sp, int64_t A, int32_t M, const T* state, con
                const T* obs, const uint8_t* obs_type, T* u_out, int32_t* status, T* rows_out,
                void* stream)
 {
+    forget_earlier_errors_();
     KArgs<T> k;
     int rc = fill_args<T>(sp, A, M, k);
     if (rc != SCCBF_OK) return rc;
@@ -327,6 +333,7 @@ int solve_step_impl(const sccbf_params* sp, double max_steer, double dt, int64_t
                     const T* u_ref, const T* obs, const uint8_t* obs_type, T* u_out, int32_t* status,
                     T* beta_out, void* stream)
 {
+    forget_earlier_errors_();
     KArgs<T> k;
     int rc = fill_args<T>(sp, A, M, k);
     if (rc != SCCBF_OK) return rc;
@@ -351,6 +358,7 @@ int solve_sa_impl(const sccbf_params* sp, double dt, int64_t A, int32_t M, const
                   const T* u_ref, const T* obs, const uint8_t* obs_type, T* u_out, int32_t* status,
                   T* rows_out, void* stream)
 {
+    forget_earlier_errors_();
     if (!sp) return SCCBF_ERR_ARG;
     sccbf_params q = *sp;
     q.dynamics = SCCBF_DYN_SADBM;
@@ -371,6 +379,7 @@ template <typename T>
 int partials_impl(const sccbf_params* sp, int64_t A, int32_t M, const T* state, const T* obs,
                   const uint8_t* obs_type, T* out, void* stream)
 {
+    forget_earlier_errors_();
     KArgs<T> k;
     int rc = fill_args<T>(sp, A, M, k);
     if (rc != SCCBF_OK) return rc;
@@ -389,6 +398,7 @@ template <typename T>
 int qp_impl(const sccbf_params* sp, int64_t A, int32_t M, const T* rows, const T* u_nom,
             T* u_out, int32_t* status, void* stream)
 {
+    forget_earlier_errors_();
     KArgs<T> k;
     sccbf_params q;
     if (!sp) return SCCBF_ERR_ARG;
@@ -421,6 +431,7 @@ template <typename T>
 int nominal_impl(const sccbf_nominal_params* sp, int64_t A, int32_t N, const T* state, const T* traj,
                  int32_t* target_idx, T* pid_state, T* u_ref, void* stream)
 {
+    forget_earlier_errors_();
     if (!sp || A < 0 || N < 1 || A > 0x7fffffffLL) return SCCBF_ERR_ARG;
     if (A == 0) return SCCBF_OK;
     if (!state || !traj || !target_idx || !u_ref) return SCCBF_ERR_ARG;
@@ -439,6 +450,7 @@ template <typename T>
 int vehicle_step_impl(int64_t A, T* state, const T* u, double lr, double lf, double max_steer, double dt,
                       T* beta_out, void* stream)
 {
+    forget_earlier_errors_();
     if (A < 0 || A > 0x7fffffffLL || !(lr > 0.0) || !(lf + lr > 0.0) || !(max_steer >= 0.0) || !std::isfinite(dt))
         return SCCBF_ERR_ARG;
     if (A == 0) return SCCBF_OK;
@@ -467,6 +479,7 @@ int rollout_impl(const sccbf_params* sp, const sccbf_nominal_params* np, const s
                  T* slip, const T* obs, const uint8_t* obs_type, T* h_min, int32_t* n_active,
                  int32_t* n_infeasible, T* trace, void* stream)
 {
+    forget_earlier_errors_();
     if (!np || !rp) return SCCBF_ERR_ARG;
     RArgs<T> r;
     int rc = fill_args<T>(sp, A, M, r.f);
@@ -520,6 +533,7 @@ template <typename T>
 int vehicle_step_kin_impl(int64_t A, T* state, const T* u, int32_t mode, double L, double max_steer, double dt,
                           void* stream)
 {
+    forget_earlier_errors_();
     if (A < 0 || A > 0x7fffffffLL || !(max_steer >= 0.0) || !std::isfinite(dt)) return SCCBF_ERR_ARG;
     if (mode != SCCBF_STEP_KIN_ACC && mode != SCCBF_STEP_KIN_VEL && mode != SCCBF_STEP_UNICYCLE) return SCCBF_ERR_ARG;
     if (mode != SCCBF_STEP_UNICYCLE && !(L > 0.0)) return SCCBF_ERR_ARG;
@@ -536,6 +550,7 @@ template <typename T>
 int ingest_impl(int64_t A, int32_t M, const T* bbox, const uint8_t* kind, double buffer, uint32_t flags,
                 T* obs, void* stream)
 {
+    forget_earlier_errors_();
     if (A < 0 || M < 0 || A > 0x7fffffffLL || M > SCCBF_MAX_ROWS || !std::isfinite(buffer)) return SCCBF_ERR_ARG;
     if (flags & ~(SCCBF_FLAG_TYPE_PER_AGENT | SCCBF_FLAG_OBS_TILED)) return SCCBF_ERR_ARG;
     if (A == 0 || M == 0) return SCCBF_OK;
@@ -552,6 +567,7 @@ int ingest_impl(int64_t A, int32_t M, const T* bbox, const uint8_t* kind, double
 template <typename T>
 int prepare_impl(int64_t A, int32_t M, T* obs, uint8_t* obs_type, uint32_t flags, void* stream)
 {
+    forget_earlier_errors_();
     if (A < 0 || M < 0 || A > 0x7fffffffLL || M > SCCBF_MAX_ROWS) return SCCBF_ERR_ARG;
     if (flags & ~(SCCBF_FLAG_TYPE_PER_AGENT | SCCBF_FLAG_OBS_TILED | SCCBF_FLAG_OBS_SHARED)) return SCCBF_ERR_ARG;
     if ((flags & SCCBF_FLAG_OBS_SHARED) && (flags & (SCCBF_FLAG_OBS_TILED | SCCBF_FLAG_TYPE_PER_AGENT)))
@@ -574,6 +590,7 @@ template <typename T>
 int lane_fit_impl(int64_t A, int32_t K, int32_t degree, const T* px, const T* py, const T* sigma, double buffer,
                   int32_t m, int32_t M, uint32_t flags, T* obs, void* stream)
 {
+    forget_earlier_errors_();
     if (A < 0 || A > 0x7fffffffLL || K < 1 || degree < 0 || degree > 3 || !std::isfinite(buffer)) return SCCBF_ERR_ARG;
     if (M < 1 || M > SCCBF_MAX_ROWS || m < 0 || m >= M) return SCCBF_ERR_ARG;
     if (flags & ~SCCBF_FLAG_OBS_TILED) return SCCBF_ERR_ARG;

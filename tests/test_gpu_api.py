@@ -171,3 +171,41 @@ def test_independent_launches_in_parallel_graph_branches(oracle):
             torch.cuda.synchronize()
             for (u, st), t in zip(want, batches):
                 assert torch.equal(u, t["u"]) and torch.equal(st, t["st"]), rep
+
+
+def test_object_api_in_a_process_that_never_imported_torch_itself():
+    """A driver script in the reference's style imports the cbf classes and numpy, not torch.  The library must
+    then still end up on the HIP runtime of the tensors it is handed (PyTorch's own copy): loaded ahead of torch it
+    would map the system's runtime and no kernel would launch."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "from sccav_cbf_amd import _lib\n"
+        "assert 'torch' not in sys.modules\n"
+        "_lib.load()\n"
+        "from sccav_cbf_amd.cbf.cbf import DBM_CBF_2DS\n"
+        "from sccav_cbf_amd.cbf.obstacles import CollisionCone2D\n"
+        "s = np.array([0.0, 5.0, 0.35, 10.0])\n"
+        "cbf = DBM_CBF_2DS(alpha=1)\n"
+        "cbf.set_model_params(lr=1.45, lf=1.45)\n"
+        "cbf.obstacle_list2d.update({0: CollisionCone2D(11.18, s, np.array([30.0, 12.0, 0.0, 0.0]))})\n"
+        "cbf.update_state(s=s)\n"
+        "cbf.set_qp_cost_weight(np.diag([0.5, 0.5]))\n"
+        "u = cbf.solve_cbf(np.array([0.3, 0.1]))\n"
+        "print('U', repr(float(u[0])), repr(float(u[1])))\n" % root)
+    env = dict(os.environ, SCCBF_NO_REBUILD="1")
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert res.returncode == 0, res.stderr[-2000:]
+    got = [float(x) for x in [l for l in res.stdout.splitlines() if l.startswith("U ")][0].split()[1:]]
+    s = np.array([0.0, 5.0, 0.35, 10.0])
+    cbf = DBM_CBF_2DS(alpha=1)
+    cbf.set_model_params(lr=1.45, lf=1.45)
+    cbf.obstacle_list2d.update({0: CollisionCone2D(11.18, s, np.array([30.0, 12.0, 0.0, 0.0]))})
+    cbf.update_state(s=s)
+    cbf.set_qp_cost_weight(np.diag([0.5, 0.5]))
+    u = cbf.solve_cbf(np.array([0.3, 0.1]))
+    assert abs(got[0] - float(u[0])) <= 1e-12 and abs(got[1] - float(u[1])) <= 1e-12
+    assert abs(got[0] - 0.3) > 1e-6 or abs(got[1] - 0.1) > 1e-6      # the cone is in the way: the filter acts
