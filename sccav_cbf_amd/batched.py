@@ -154,6 +154,10 @@ class BatchedCBF:
             return u_out, status, rows_out
         return u_out, status
 
+    def prepare_obs(self, obs, obs_type, agents=None):
+        """As-written ellipse / cone slots -> their prepared kinds, in place: the module's prepare_obs()."""
+        return prepare_obs(obs, obs_type, agents)
+
     def solve_qp(self, rows, u_nom, u_out=None, status=None):
         """QP stage alone: rows (M,A,4) = a0, a1, b, - with a.u >= b; u_nom (A,2)."""
         if not rows.is_cuda:
@@ -281,9 +285,14 @@ def capture_independent(launches, branches=3, stream=None):
     in flight one loads while another computes: 5.7 instead of 9.1 us per launch on an MI355X.  Launches that
     depend on each other (the ticks of one closed loop) belong on one branch: `branches=1`.
     Call every launch once eagerly first (warm-up, and kernels that need more than 64 KB of LDS set their
-    attribute then).  Returns the torch.cuda.CUDAGraph; replay() runs on the stream it was captured on."""
+    attribute then).  stream: the capture stream (default: the current stream, or a new one when that is the
+    default stream, which cannot capture).  Returns the torch.cuda.CUDAGraph; replay() enqueues it on the stream
+    that is current then."""
     launches = list(launches)
-    stream = stream or torch.cuda.current_stream()
+    cur = torch.cuda.current_stream()
+    if stream is None:
+        stream = cur if cur != torch.cuda.default_stream(cur.device) else torch.cuda.Stream(cur.device)
+    stream.wait_stream(cur)        # what the caller enqueued so far comes first
     branches = max(1, min(int(branches), len(launches)))
     side = [torch.cuda.Stream(stream.device) for _ in range(branches - 1)]
     g = torch.cuda.CUDAGraph()
@@ -295,5 +304,6 @@ def capture_independent(launches, branches=3, stream=None):
                 f()
         for s in side:
             stream.wait_stream(s)
-    g._sccbf_streams = side      # the side streams live as long as the graph
+    cur.wait_stream(stream)
+    g._sccbf_streams = side + [stream]      # the streams live as long as the graph
     return g
