@@ -24,14 +24,14 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, A, tiled, ret):
+def _worker(rank, world, port, A, tiled, ret, backend="gloo"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group(backend, rank=rank, world_size=world)
     try:
         from sccav_cbf_amd.batched import BatchedCBF
-        dev = torch.device("cuda", 0)
-        torch.cuda.set_device(dev)
         flt = BatchedCBF(alpha=1.0, R=np.diag([0.5, 0.5]))
         M = 16
         batch = None
@@ -39,6 +39,8 @@ def _worker(rank, world, port, A, tiled, ret):
             w = scenarios.config4(A=A, nominal="uniform")
             batch = {k: torch.from_numpy(v) for k, v in w.items()}
             batch = {k: (v.float() if v.dtype.is_floating_point else v) for k, v in batch.items()}
+            if backend == "nccl":          # RCCL moves device memory
+                batch = {k: v.to(dev) for k, v in batch.items()}
         from sccav_cbf_amd.batched import planes_to_tiled
         planes = None
         if rank == 0 and tiled:      # the layout the benchmark uses: a rank's tiles are one contiguous block
@@ -78,4 +80,20 @@ def test_two_ranks_on_the_gpu_scatter_solve_gather(tiled):
             for p in ctx.processes:
                 p.terminate()
             pytest.fail("ranks did not finish in 150 s")
+    assert ret["n"] == A and ret["equal"] and ret["active"] > 1000
+
+
+def test_one_rank_over_rccl_scatter_solve_gather():
+    """The same path with the collectives on RCCL (backend "nccl", device tensors, no host copies): one rank, which is
+    all a one-GPU box can start; broadcast and all-gather run through the library all the same."""
+    A = 5001
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    ctx = mp.spawn(_worker, args=(1, _free_port(), A, True, ret, "nccl"), nprocs=1, join=False)
+    t0 = time.time()
+    while not ctx.join(timeout=5):
+        if time.time() - t0 > 150:
+            for p in ctx.processes:
+                p.terminate()
+            pytest.fail("the rank did not finish in 150 s")
     assert ret["n"] == A and ret["equal"] and ret["active"] > 1000
