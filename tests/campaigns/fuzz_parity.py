@@ -21,10 +21,22 @@ from tests.test_gpu_parity import _near_feasibility_boundary  # noqa: E402
 DEV = torch.device("cuda", 0)
 
 
-def random_case(rng, A, M):
+def random_case(rng, A, M, special_p=0.0):
     state = np.stack([rng.uniform(-50, 50, A), rng.uniform(0, 30, A), rng.uniform(-3.1, 3.1, A),
                       rng.uniform(0.1, 15, A)], axis=1)
     state[rng.uniform(size=A) < 0.05, 3] = 0.0       # at rest: rows without dh/dv lose their normal altogether
+    special = np.zeros(A, dtype=bool)
+    if special_p > 0:
+        # special values, which uniform draws all but never produce: headings on and within 1e-7 ... 1e-3 of the axes
+        # (either side), and further down cones that move with the agent's own velocity to 1e-6 ... 1e-2 and stand
+        # with the agent on their rim
+        special = rng.uniform(size=A) < special_p
+        n = int(special.sum())
+        base = rng.choice([0.0, 0.5 * np.pi, -0.5 * np.pi, np.pi, -np.pi], n)
+        tiny = np.where(rng.uniform(size=n) < 0.2, 0.0, 10.0 ** rng.uniform(-7, -3, n)) * rng.choice([-1.0, 1.0], n)
+        th = base + tiny
+        th = np.where(th > np.pi, 2 * np.pi - th, np.where(th < -np.pi, -2 * np.pi - th, th))   # stay inside [-pi, pi]
+        state[special, 2] = th
     u_ref = np.stack([rng.uniform(-2, 2, A), rng.uniform(-0.5, 0.5, A)], axis=1)
     kinds = rng.choice([0, 1, 2, 3, 255], size=M, p=[0.3, 0.3, 0.1, 0.2, 0.1]).astype(np.uint8)
     slots = np.zeros((M, A, 8))
@@ -37,6 +49,17 @@ def random_case(rng, A, M):
         elif k == 1:
             slots[m] = np.stack([cx, cy, rng.uniform(-3.1, 3.1, A), rng.uniform(0, 6, A), rng.uniform(2, 7, A),
                                  rng.choice([0.0, 0.1, -0.2], A), np.zeros(A), np.zeros(A)], axis=1)
+            if special.any():
+                n = int(special.sum())
+                sl = slots[m][special]
+                sl[:, 2] = state[special, 2]                                                   # the agent's heading,
+                sl[:, 3] = state[special, 3] * (1.0 + rng.choice([-1.0, 1.0], n) * 10.0 ** rng.uniform(-6, -2, n))  # its speed
+                sl[:, 5] = 0.0
+                rim = rng.uniform(size=n) < 0.5                                                # and half of them on the rim
+                d = np.where(rim, sl[:, 4] * (1.0 + rng.choice([-1.0, 1.0], n) * 10.0 ** rng.uniform(-7, -3, n)), rg[special])
+                sl[:, 0] = state[special, 0] + d * np.cos(br[special])
+                sl[:, 1] = state[special, 1] + d * np.sin(br[special])
+                slots[m][special] = sl
         elif k == 2:    # a gently curved lane boundary above or below the agents
             side = rng.choice([-1.0, 1.0])
             slots[m] = np.stack([np.full(A, 15.0 + side * 12.0), rng.uniform(-0.05, 0.05, A), rng.uniform(-1e-3, 1e-3, A),
@@ -70,6 +93,9 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--agents", type=int, default=1024)
     ap.add_argument("--only", type=int, default=-1, help="replay the random stream but run (and detail) only this case")
+    ap.add_argument("--special", type=float, default=0.0,
+                    help="share of the agents given special values (headings on the axes and next to them, cones at the "
+                         "agent's own velocity and with the agent on their rim); 0 keeps the random stream of earlier runs")
     args = ap.parse_args()
     rng = np.random.default_rng(args.seed)
     orc.build()
@@ -77,7 +103,7 @@ def main():
     for case in range(args.cases):
         M = int(rng.choice([1, 2, 3, 4, 7, 8, 12, 16, 17, 24, 32, 48, 64, 100, 257]))
         A = (args.agents if M <= 64 else 128) + int(rng.integers(0, 70))
-        state, u_ref, obs, kinds = random_case(rng, A, M)
+        state, u_ref, obs, kinds = random_case(rng, A, M, args.special)
         q = rng.normal(size=(2, 2))
         R = q @ q.T + 0.3 * np.eye(2)
         alpha = float(rng.choice([0.3, 1.0, 4.0]))
@@ -131,9 +157,11 @@ def main():
                 return orc.solve_sa_batch(p, sa_dt, rnd(state), rnd(sa_slip), rnd(u_given), rnd(obs), ty, want_rows=True)[2]
             return orc.solve_batch(p, rnd(state), rnd(u_given), rnd(obs), ty, want_rows=True)[2]
 
+        jrng = np.random.default_rng([args.seed, case])   # its own stream: --only replays a case exactly
+
         def jitter(v):      # every value one fp32 ulp up or down at random
             f = v.astype(np.float32)
-            return np.where(rng.integers(0, 2, f.shape) == 1, np.nextafter(f, np.float32(np.inf)),
+            return np.where(jrng.integers(0, 2, f.shape) == 1, np.nextafter(f, np.float32(np.inf)),
                             np.nextafter(f, np.float32(-np.inf))).astype(np.float64)
         ro32 = rows_of(r32)
         sens = np.abs(ro - ro32)
