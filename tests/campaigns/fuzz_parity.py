@@ -257,6 +257,11 @@ def main():
                 uq, sq = orc.qp_batch(pq, rq, un)
                 far = ((sq == 0) & (np.abs(uq - un).max(axis=1) > 1e3)) | ((st == 0) & (np.abs(u - un).max(axis=1) > 1e3))
                 idx = np.where((st != sq) & (st != 2) & ~far)[0]
+                # ... or where the optimum (the exact one, or the GPU's) sits on two rows that single precision cannot
+                # tell from parallel (|sin| < 1e-5; the kernel's own threshold is 1e-6): facing each other such rows
+                # leave a wedge a few ulp wide, which exists or not by the last bits
+                wedge = np.where(sq[idx] == 0, parity.active_det(uq, rq)[idx], parity.active_det(u, rq)[idx]) < 1e-5
+                idx = idx[~wedge]
                 if idx.size and not all(_near_feasibility_boundary(idx[k:k + 1], sq, rq, un, R) for k in range(idx.size)):
                     misses += 1
                     print("MISS f32 status %s: %d of %d agents differ from the exact QP on the same rows without a far "
@@ -271,11 +276,18 @@ def main():
                 both = (st == 0) & (sq == 0)
                 det = parity.active_det(uq, rq)
                 ok = both & (det >= 1e-2) & (np.abs(uq - un).max(axis=1) <= 50)
-                dq = np.abs(u - uq).max(axis=1) / np.maximum(1.0, np.hypot(uq[:, 0], uq[:, 1]))
-                if ok.any() and dq[ok].max() > 1e-3:
+                uscale = np.maximum(1.0, np.hypot(uq[:, 0], uq[:, 1]))
+                dq = np.abs(u - uq).max(axis=1) / uscale
+                # a row enters the QP as its distance from the nominal input, (b - a . u_nom) / |a|: where b and
+                # a . u_nom nearly cancel, an fp32 ulp of either (4 of them allowed) is an error of that distance, and a
+                # vertex moves by it over |sin|
+                nrm = np.hypot(rq[:, :, 0], rq[:, :, 1]) + 1e-300
+                canc = ((np.abs(rq[:, :, 2]) + np.abs(rq[:, :, 0] * un[None, :, 0]) + np.abs(rq[:, :, 1] * un[None, :, 1])) / nrm).max(axis=0)
+                tolq = 1e-3 + 4.0 * 6e-8 * canc / (det * uscale)
+                if ok.any() and (dq[ok] > tolq[ok]).any():
                     misses += 1
-                    a = int(np.argmax(np.where(ok, dq, 0)))
-                    print("MISS f32 qp %s: agent %d du %.3g det %.3g" % (tag, a, dq[a], det[a]), flush=True)
+                    a = int(np.argmax(np.where(ok, dq - tolq, -np.inf)))
+                    print("MISS f32 qp %s: agent %d du %.3g (allowed %.3g) det %.3g" % (tag, a, dq[a], tolq[a], det[a]), flush=True)
                 # for the record: distance to the oracle's answer among well-conditioned optima
                 both = (st == 0) & (so == 0)
                 ok = both & (parity.active_det(uo, ro) >= 1e-2) & (np.abs(uo - u_ref).max(axis=1) <= 50)
