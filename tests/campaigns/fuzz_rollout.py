@@ -75,6 +75,8 @@ def main():
                     help="f32: the two fp32 paths round differently tick by tick, so an agent is judged while an fp32 "
                          "ulp on the data stays below 3e-6, to 5e-2 (a detector of gross errors: a wrong slot, kind or "
                          "tick order moves the inputs by O(1))")
+    ap.add_argument("--special", type=float, default=0.0,
+                    help="share of the agents given special values, as in fuzz_parity.py (0 keeps the stream of earlier runs)")
     args = ap.parse_args()
     rng = np.random.default_rng(args.seed)
     orc.build()
@@ -86,7 +88,7 @@ def main():
         M = int(rng.choice([1, 2, 3, 4, 5, 8, 12, 16, 17, 31, 32, 33, 48, 64]))
         A = int(rng.integers(1, 400))
         T = int(rng.integers(1, 25))
-        state, _, obs, kinds = random_case(rng, A, M)
+        state, _, obs, kinds = random_case(rng, A, M, args.special)
         N = int(rng.choice([0, 1, 2, 33, 500, 2034, 2048]))
         motion = str(rng.choice(["static", "constant_velocity", "seeker"]))
         per_agent, tiled, pid, wps = (bool(rng.integers(0, 2)) for _ in range(4))
