@@ -635,7 +635,7 @@ def worker(args):
             except Exception as e:
                 out["fp64"] = {"error": repr(e)}
         if world == 1 and not stub and not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         if _saved_stdout is not None:
             sys.stdout.flush()
             os.dup2(_saved_stdout, 1)
@@ -655,6 +655,8 @@ def main():
     ap.add_argument("--agents", type=int, default=AGENTS)
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0,
+                    help="length of the all-threads sample of the CPU baseline (the one-thread sample takes 0.4 of it)")
     ap.add_argument("--planes", action="store_true", help="obstacles as (M,2,A,4) planes instead of 64-agent tiles")
     ap.add_argument("--slots", choices=("prepared", "written"), default="prepared",
                     help="ellipse / cone slots with their per-obstacle constants evaluated (default) or as the "
