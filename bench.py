@@ -520,6 +520,33 @@ def worker(args):
                 steady = {"steps": n_st * 10 * RING, "ms_per_step": st_ms, "value": A / (st_ms * 1e-3),
                           "launch": "hipGraphs of %d launches in %d parallel branch(es)" % (10 * RING, nb),
                           "note": "this rank, wall clock, outside the timed region"}
+                if nb > 1:
+                    # the other way to keep three launches in flight: one SERIAL graph per stream, three streams side
+                    # by side (no fork / join inside a graph; a third of the host time per launch)
+                    from sccav_cbf_amd.batched import capture_independent
+                    ss = [torch.cuda.Stream(device) for _ in range(3)]
+                    gs = []
+                    for j, s_ in enumerate(ss):
+                        s_.wait_stream(stream)
+                        with torch.cuda.stream(s_):
+                            gs.append(capture_independent([(lambda i=i: step(i)) for i in range(j, 30 * RING, 3)], 1, s_))
+
+                    def walk(n):
+                        for _ in range(n):
+                            for s_, g_ in zip(ss, gs):
+                                with torch.cuda.stream(s_):
+                                    g_.replay()
+                    walk(20)
+                    torch.cuda.synchronize()
+                    n_w = 70
+                    ts = time.perf_counter()
+                    walk(n_w)
+                    torch.cuda.synchronize()
+                    w_ms = (time.perf_counter() - ts) * 1e3 / (n_w * 30 * RING)
+                    steady["three_streams"] = {"steps": n_w * 30 * RING, "ms_per_step": w_ms, "value": A / (w_ms * 1e-3),
+                                               "launch": "a serial hipGraph of %d launches on each of 3 streams" % (10 * RING)}
+                    for s_ in ss:
+                        stream.wait_stream(s_)
 
     # max over ranks of the timed region; every rank's own time; proof that the collective
     # library saw every rank (a sum of ones over the process group)
@@ -608,6 +635,9 @@ def worker(args):
             out["roofline"]["overlapped_answers_equal_serial"] = bool(same_answers)
         if not stub and steady is not None:
             steady["roofline_frac"] = abytes / (steady["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBPS
+            if "three_streams" in steady:
+                steady["three_streams"]["roofline_frac"] = (abytes / (steady["three_streams"]["ms_per_step"] * 1e-3) / 1e9
+                                                            / HBM_PEAK_GBPS)
             out["steady_state"] = steady
         if stub:
             out["data"] = "none (cpu stub: launcher rehearsal, nothing measured)"
