@@ -1,5 +1,5 @@
-"""The examples of INTEGRATION.md, run as a user would: in a fresh process, written the way the document writes
-them (names filled in), every result checked for shape and sanity.  Needs an MI355X."""
+"""The usage examples of the integration guide, run as a user would: in a fresh process, written the way the guide
+writes them (names filled in), every result checked for shape and sanity.  Needs an MI355X."""
 import os
 import subprocess
 import sys
