@@ -66,7 +66,7 @@
 extern "C" {
 #endif
 
-#define SCCBF_VERSION 201 /* 0.2.1 */
+#define SCCBF_VERSION 300 /* 0.3.0 */
 
 /* obstacle kinds: 0..2 follow Obstacle2DTypes, reference cbf/obstacles.py:51-57 */
 #define SCCBF_OBS_ELLIPSE 0
@@ -179,6 +179,42 @@ int sccbf_solve_f64(const sccbf_params* p, int64_t A, int32_t M,
                     const double* obs, const uint8_t* obs_type,
                     double* u_out, int32_t* status, double* rows_out,
                     void* stream);
+
+/*
+ * K independent batches of sccbf_solve_* in ONE launch: the same filter (DBM_CBF_2DS.solve_cbf, reference
+ * cbf/cbf.py:166-220, KBM_VC_CBF2D.solve_cbf, 67-110, with the obstacle partials of cbf/obstacles.py named at
+ * sccbf_solve_*), for callers whose agents arrive as separate batches, each with its own arrays: the
+ * scenarios of a Monte-Carlo sweep, the clients of one serving tick.  A launch of 65536 agents x 16 rows ends
+ * before its loads and its arithmetic have anything to overlap with (half of the memory rate); the same
+ * agents as sixteen batches of one launch run at the rate of a 2^20-agent launch.  Answers are those of K
+ * sccbf_solve_* calls, bit for bit.
+ *   batches  DEVICE array of K records, owned by the caller and read by the kernel while it runs: per batch
+ *            the number of agents and the arrays of sccbf_solve_* (rows_out optional).  Batches may differ
+ *            in size.  The kernel SKIPS a record it cannot serve and writes none of its outputs: A <= 0,
+ *            A > A_max, or a required pointer missing (a caller that fills status with a sentinel sees it).
+ *   M, p     shared by all batches (p->flags say how every batch lays out obs and obs_type);
+ *            dynamics SCCBF_DYN_DBM or SCCBF_DYN_KBM
+ *   A_max    the largest A among the records (the host cannot read them): sizes the grid, < 2^31;
+ *            0 = nothing to do
+ *   K        0 ... SCCBF_MAX_BATCHES
+ */
+typedef struct sccbf_batch {
+    int64_t A;
+    const void* state;    /* T[A][4] */
+    const void* u_ref;    /* T[A][2] */
+    const void* obs;      /* layout by p->flags, M slots */
+    const void* obs_type; /* u8[M] or u8[M][A] */
+    void* u_out;          /* T[A][2] */
+    void* status;         /* i32[A] */
+    void* rows_out;       /* T[M][A][4] or NULL */
+} sccbf_batch;
+
+#define SCCBF_MAX_BATCHES 65535
+
+int sccbf_solve_batches_f32(const sccbf_params* p, int32_t K, int32_t M, int64_t A_max,
+                            const sccbf_batch* batches, void* stream);
+int sccbf_solve_batches_f64(const sccbf_params* p, int32_t K, int32_t M, int64_t A_max,
+                            const sccbf_batch* batches, void* stream);
 
 /*
  * Steer-rate model: SADBM_CBF_2DS.solve_cbf, reference cbf/cbf.py:349-437, for A agents.

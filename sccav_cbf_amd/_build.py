@@ -23,7 +23,7 @@ HIPCC_FLAGS = [
 # parts of the one source file (sccbf.hip says which entry points each holds) and their extra flags:
 # the fp64 rollout is compiled without machine-level loop-invariant hoisting, which would keep the
 # double-precision constants of the library transcendentals in registers across its tick loop
-PARTS = [("F32", []), ("F64", []), ("ROLLOUT_F64", ["-mllvm", "-disable-machine-licm"])]
+PARTS = [("F32", []), ("F64", []), ("ROLLOUT_F64", ["-mllvm", "-disable-machine-licm"]), ("BATCHES", [])]
 
 
 def needs_build():

@@ -8,7 +8,7 @@ import os
 from . import _build
 from ._build import LIB
 
-ABI_VERSION = 201   # SCCBF_VERSION of include/sccbf.h this binding was written against
+ABI_VERSION = 300   # SCCBF_VERSION of include/sccbf.h this binding was written against
 
 OBS_ELLIPSE, OBS_CONE, OBS_LANE, OBS_RADIAL, OBS_EMPTY = 0, 1, 2, 3, 255
 OBS_ELLIPSE_PREP, OBS_CONE_PREP = 4, 5   # the same obstacles, per-obstacle constants already evaluated
@@ -29,7 +29,7 @@ EXPORTS = ("sccbf_version", "sccbf_strerror", "sccbf_default_params", "sccbf_sol
            "sccbf_solve_sa_f32", "sccbf_solve_sa_f64", "sccbf_ingest_bbox_f32", "sccbf_ingest_bbox_f64",
            "sccbf_lane_fit_f32", "sccbf_lane_fit_f64", "sccbf_solve_step_f32", "sccbf_solve_step_f64",
            "sccbf_prepare_obs_f32", "sccbf_prepare_obs_f64", "sccbf_vehicle_step_kin_f32",
-           "sccbf_vehicle_step_kin_f64")
+           "sccbf_vehicle_step_kin_f64", "sccbf_solve_batches_f32", "sccbf_solve_batches_f64")
 MOTION_STATIC, MOTION_CONSTANT_VELOCITY, MOTION_SEEKER = 0, 1, 2
 STEP_KIN_ACC, STEP_KIN_VEL, STEP_UNICYCLE = 0, 1, 2
 NOMINAL_WAYPOINT_SPEED = 1
@@ -53,6 +53,15 @@ class RolloutParams(C.Structure):
     """struct sccbf_rollout_params of include/sccbf.h."""
     _fields_ = [("max_steer", C.c_double), ("dt", C.c_double), ("ticks", C.c_int32), ("motion", C.c_int32),
                 ("seek_gain", C.c_double), ("seek_v_min", C.c_double)]
+
+
+class Batch(C.Structure):
+    """struct sccbf_batch of include/sccbf.h: one batch of sccbf_solve_batches_* (64 bytes)."""
+    _fields_ = [("A", C.c_int64), ("state", C.c_void_p), ("u_ref", C.c_void_p), ("obs", C.c_void_p),
+                ("obs_type", C.c_void_p), ("u_out", C.c_void_p), ("status", C.c_void_p), ("rows_out", C.c_void_p)]
+
+
+MAX_BATCHES = 65535
 
 
 class SccbfError(RuntimeError):
@@ -155,6 +164,10 @@ def _bind(L):
         f = getattr(L, name)
         f.restype = C.c_int
         f.argtypes = [C.c_int64, vp, vp, C.c_int32, C.c_double, C.c_double, C.c_double, vp]
+    for name in ("sccbf_solve_batches_f32", "sccbf_solve_batches_f64"):
+        f = getattr(L, name)
+        f.restype = C.c_int
+        f.argtypes = [C.POINTER(Params), C.c_int32, C.c_int32, C.c_int64, vp, vp]
     _lib = L
     return L
 

@@ -154,6 +154,22 @@ class BatchedCBF:
             return u_out, status, rows_out
         return u_out, status
 
+    def solve_batches(self, table, first=0, count=None):
+        """One launch for `count` batches of a BatchTable from record `first` on (default: all of them):
+        sccbf_solve_batches_*, the answers of solve() called per batch, bit for bit, at the memory rate of
+        one launch over all their agents.  Dynamics "dbm" or "kbm".  Asynchronous on the current stream."""
+        K = len(table) - first if count is None else int(count)
+        if first < 0 or K < 0 or first + K > len(table):
+            raise ValueError("batches %d ... %d of a table of %d" % (first, first + K, len(table)))
+        self.params.flags = (table.flags | (FLAG_SLIP_IO if self.slip_io else 0)
+                             | (_lib.FLAG_OBS_STREAMED if self.streamed_obs else 0))
+        fn = self._lib.sccbf_solve_batches_f32 if table.dtype == torch.float32 else self._lib.sccbf_solve_batches_f64
+        with torch.cuda.device(table.device):
+            stream = torch.cuda.current_stream(table.device).cuda_stream
+            rc = fn(C.byref(self.params), K, table.M, table.a_max(first, K),
+                    C.c_void_p(table.records.data_ptr() + 64 * first), C.c_void_p(stream))
+        _lib.check(rc)
+
     def prepare_obs(self, obs, obs_type, agents=None):
         """As-written ellipse / cone slots -> their prepared kinds, in place: the module's prepare_obs()."""
         return prepare_obs(obs, obs_type, agents)
@@ -178,6 +194,61 @@ class BatchedCBF:
                     C.c_void_p(stream))
         _lib.check(rc)
         return u_out, status
+
+
+class BatchTable:
+    """The batches of BatchedCBF.solve_batches: a device array of sccbf_batch records (include/sccbf.h) and the
+    tensors they point to.  batches: dicts with state (A,4), u_ref (A,2), obs, obs_type as solve() takes them,
+    and optionally u_out (A,2), status (A,), rows_out (M,A,4) (made here when missing; rows only with
+    want_rows).  All batches share dtype, device, M and the layout of obs / obs_type; A may differ.
+    Build it once and launch it every tick: the records hold addresses, the tensors may be rewritten in place."""
+
+    def __init__(self, batches, want_rows=False):
+        batches = [dict(b) for b in batches]
+        if not batches:
+            raise ValueError("no batches")
+        b0 = batches[0]
+        if not b0["state"].is_cuda:
+            raise _lib.SccbfError("BatchTable needs tensors on the GPU (no CPU fallback)")
+        self.dtype, self.device = b0["state"].dtype, b0["state"].device
+        if self.dtype not in (torch.float32, torch.float64):
+            raise TypeError("state must be float32 or float64")
+        od, td = b0["obs"].dim(), b0["obs_type"].dim()
+        self.M = b0["obs"].shape[1] if od == 5 else b0["obs"].shape[0]
+        self.flags = ({5: FLAG_OBS_TILED, 3: FLAG_OBS_SHARED}.get(od, 0)
+                      | (FLAG_TYPE_PER_AGENT if td == 2 else 0))
+        dt, dev, M = self.dtype, self.device, self.M
+        rec = np.zeros((len(batches), 8), dtype=np.int64)
+        for i, b in enumerate(batches):
+            A = b["state"].shape[0]
+            exp_obs = {5: ((A + 63) // 64, M, 2, 64, 4), 3: (M, 2, 4)}.get(od, (M, 2, A, 4))
+            b.setdefault("u_out", torch.empty((A, 2), dtype=dt, device=dev))
+            b.setdefault("status", torch.empty((A,), dtype=torch.int32, device=dev))
+            if want_rows:
+                b.setdefault("rows_out", torch.empty((M, A, 4), dtype=dt, device=dev))
+            for name, shape, dtype in (("state", (A, 4), dt), ("u_ref", (A, 2), dt), ("obs", exp_obs, dt),
+                                       ("obs_type", (M, A) if td == 2 else (M,), torch.uint8),
+                                       ("u_out", (A, 2), dt), ("status", (A,), torch.int32),
+                                       ("rows_out", (M, A, 4), dt)):
+                t = b.get(name)
+                if t is None and name == "rows_out":
+                    continue
+                if (t is None or tuple(t.shape) != shape or t.dtype != dtype or t.device != dev
+                        or not t.is_contiguous()):
+                    raise ValueError("batch %d, %s: expected contiguous %s %s on %s" % (i, name, shape, dtype, dev))
+            rec[i] = [A] + [b[k].data_ptr() for k in ("state", "u_ref", "obs", "obs_type", "u_out", "status")] + [
+                b["rows_out"].data_ptr() if b.get("rows_out") is not None else 0]
+        self.batches = batches                      # keeps the tensors alive
+        self.agents = [int(a) for a in rec[:, 0]]
+        self.host_records = rec                     # (K, 8) int64: struct sccbf_batch as the ABI lays it out
+        self.records = torch.from_numpy(rec).to(dev)
+
+    def __len__(self):
+        return len(self.batches)
+
+    def a_max(self, first=0, count=None):
+        part = self.agents[first:] if count is None else self.agents[first:first + count]
+        return max(part) if part else 0
 
 
 def prepare_obs(obs, obs_type, agents=None):

@@ -32,28 +32,39 @@
 #include "sccbf_loop.hip.h"
 #include "sccbf_ext.hip.h"
 #include "sccbf_ingest.hip.h"
+#include "sccbf_batches.hip.h"
 
 // The library is built from this one source in three parts that compile side by side (_build.py):
 // the fp32 entry points, the fp64 ones, and sccbf_rollout_f64 on its own, because that part is compiled
 // without the machine-level hoisting of loop invariants: with it, the 50 double-precision constants of the
 // library tan / atan / atan2 / sincos are parked in registers across the tick loop, 358 registers per lane
-// and one wavefront per SIMD; without it 256 and two, with nothing spilled.  No macro: everything.
+// and one wavefront per SIMD; without it 256 and two, with nothing spilled.  The fourth part holds the
+// entry points that solve several batches in one launch, in both precisions.  No macro: everything.
 #if defined(SCCBF_ONLY_F32)
 #define SCCBF_HAS_F32 1
 #define SCCBF_HAS_F64 0
 #define SCCBF_HAS_ROLLOUT_F64 0
+#define SCCBF_HAS_BATCHES 0
 #elif defined(SCCBF_ONLY_F64)
 #define SCCBF_HAS_F32 0
 #define SCCBF_HAS_F64 1
 #define SCCBF_HAS_ROLLOUT_F64 0
+#define SCCBF_HAS_BATCHES 0
 #elif defined(SCCBF_ONLY_ROLLOUT_F64)
 #define SCCBF_HAS_F32 0
 #define SCCBF_HAS_F64 0
 #define SCCBF_HAS_ROLLOUT_F64 1
+#define SCCBF_HAS_BATCHES 0
+#elif defined(SCCBF_ONLY_BATCHES)
+#define SCCBF_HAS_F32 0
+#define SCCBF_HAS_F64 0
+#define SCCBF_HAS_ROLLOUT_F64 0
+#define SCCBF_HAS_BATCHES 1
 #else
 #define SCCBF_HAS_F32 1
 #define SCCBF_HAS_F64 1
 #define SCCBF_HAS_ROLLOUT_F64 1
+#define SCCBF_HAS_BATCHES 1
 #endif
 
 namespace {
@@ -623,9 +634,120 @@ int lane_fit_impl(int64_t A, int32_t K, int32_t degree, const T* px, const T* py
     return hipGetLastError() == hipSuccess ? SCCBF_OK : SCCBF_ERR_LAUNCH;
 }
 
+
+// ------------------------------------------------------------- several batches, one launch
+template <typename T, int G, int RPL>
+int launch_group_batches(const KArgs<T>& k, const sccbf_batch* table, int K, long long a_max, bool nt, hipStream_t s)
+{
+    const long long per_block = kBlock / G;
+    const long long bx = (a_max + per_block - 1) / per_block;
+    if (bx > 0x7fffffffLL) return SCCBF_ERR_ARG;
+    const dim3 grid((unsigned)bx, (unsigned)K);
+    if (nt) hipLaunchKernelGGL((k_group_batches<T, G, RPL, true>), grid, dim3(kBlock), 0, s, table, k.M, k.flags, k);
+    else hipLaunchKernelGGL((k_group_batches<T, G, RPL, false>), grid, dim3(kBlock), 0, s, table, k.M, k.flags, k);
+    return hipGetLastError() == hipSuccess ? SCCBF_OK : SCCBF_ERR_LAUNCH;
+}
+
+template <typename T, int G>
+int launch_group_batches_rpl(const KArgs<T>& k, const sccbf_batch* table, int K, long long a_max, bool nt, hipStream_t s)
+{
+    const int rpl = (k.M + G - 1) / G;
+    if (rpl <= 1) return launch_group_batches<T, G, 1>(k, table, K, a_max, nt, s);
+    if (rpl <= 2) return launch_group_batches<T, G, 2>(k, table, K, a_max, nt, s);
+    if (rpl <= 4) return launch_group_batches<T, G, 4>(k, table, K, a_max, nt, s);
+    if (rpl <= 8) return launch_group_batches<T, G, 8>(k, table, K, a_max, nt, s);
+    if (rpl <= 16) return launch_group_batches<T, G, 16>(k, table, K, a_max, nt, s);
+    return SCCBF_ERR_VARIANT;
+}
+
+template <typename T, int G, int QPB, bool PAIRED>
+int launch_wave_batches_shape(const KArgs<T>& k, const sccbf_batch* table, int K, long long a_max, hipStream_t s)
+{
+    const size_t lds = wave_lds<T>(k.M, QPB);
+    const long long bx = wave_blocks<QPB, PAIRED>(a_max);
+    if (bx > 0x7fffffffLL) return SCCBF_ERR_ARG;
+    if (!grant_lds<k_wave_batches<T, QPB, G, PAIRED>>(lds)) return SCCBF_ERR_VARIANT;
+    hipLaunchKernelGGL((k_wave_batches<T, QPB, G, PAIRED>), dim3((unsigned)bx, (unsigned)K), dim3(QPB * G), lds, s, table,
+                       k.M, k.flags, k);
+    return hipGetLastError() == hipSuccess ? SCCBF_OK : SCCBF_ERR_LAUNCH;
+}
+
+template <typename T, int G>
+int launch_wave_batches(const KArgs<T>& k, const sccbf_batch* table, int K, long long a_max, hipStream_t s)
+{
+    constexpr int kQpb = WaveShape<T, G>::kQpb;
+    if (G == 64 && wave_paired<T>(k.M))
+        return launch_wave_batches_shape<T, G, (G == 64 ? kQpb / 2 : kQpb), G == 64>(k, table, K, a_max, s);
+    return launch_wave_batches_shape<T, G, kQpb, false>(k, table, K, a_max, s);
+}
+
+// The launch of K batches whose records already lie in device memory at `table`.
+template <typename T>
+int batches_launch(const sccbf_params* sp, int32_t K, int32_t M, int64_t a_max, const sccbf_batch* table, void* stream)
+{
+    if (K < 0 || K > SCCBF_MAX_BATCHES || a_max < 0) return SCCBF_ERR_ARG;
+    KArgs<T> k;
+    int rc = fill_args<T>(sp, a_max, M, k);
+    if (rc != SCCBF_OK) return rc;
+    // the models of sccbf_solve_* whose kernels take nothing but these arrays; no shared-nothing flags beyond its own
+    if (sp->dynamics != SCCBF_DYN_DBM && sp->dynamics != SCCBF_DYN_KBM) return SCCBF_ERR_ARG;
+    if (sp->flags & SCCBF_FLAG_CONE_BETA_STATE) return SCCBF_ERR_ARG;
+    if (K == 0 || a_max == 0) return SCCBF_OK;
+    if (!table) return SCCBF_ERR_ARG;
+    k.state = nullptr; k.u_ref = nullptr; k.obs = nullptr; k.obs_type = nullptr;
+    k.u_out = nullptr; k.status = nullptr; k.rows_out = nullptr;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (M == 0) {
+        const long long bx = (a_max + kBlock - 1) / kBlock;
+        if (bx > 0x7fffffffLL) return SCCBF_ERR_ARG;
+        hipLaunchKernelGGL((k_passthrough_batches<T>), dim3((unsigned)bx, (unsigned)K), dim3(kBlock), 0, s, table, k);
+        return hipGetLastError() == hipSuccess ? SCCBF_OK : SCCBF_ERR_LAUNCH;
+    }
+    // lanes per QP as for one launch over all the agents (the batches fill the GPU together)
+    const double total = (double)a_max * K;
+    const int64_t a_all = total > 2147483647.0 ? 0x7fffffffLL : (int64_t)total;
+    int lanes = sp->lanes_per_qp;
+    if (lanes == 0) lanes = auto_lanes(a_all, M);
+    if (lanes == 64 && sp->lanes_per_qp == 0) lanes = wave_lanes<T>(M);
+    const bool nt = (sp->flags & SCCBF_FLAG_OBS_STREAMED) || total * M * 8 * sizeof(T) >= kNtBytes;
+    switch (lanes) {
+    case 1: return launch_group_batches_rpl<T, 1>(k, table, K, a_max, nt, s);
+    case 2: return launch_group_batches_rpl<T, 2>(k, table, K, a_max, nt, s);
+    case 4: return launch_group_batches_rpl<T, 4>(k, table, K, a_max, nt, s);
+    case 8: return launch_group_batches_rpl<T, 8>(k, table, K, a_max, nt, s);
+    case 16: return M <= 128 ? launch_group_batches_rpl<T, 16>(k, table, K, a_max, nt, s)
+                             : launch_wave_batches<T, 16>(k, table, K, a_max, s);
+    case 32: return launch_wave_batches<T, 32>(k, table, K, a_max, s);
+    case 64: return launch_wave_batches<T, 64>(k, table, K, a_max, s);
+    default: return SCCBF_ERR_VARIANT;
+    }
+}
+
+template <typename T>
+int solve_batches_impl(const sccbf_params* sp, int32_t K, int32_t M, int64_t a_max, const sccbf_batch* table,
+                       void* stream)
+{
+    forget_earlier_errors_();
+    return batches_launch<T>(sp, K, M, a_max, table, stream);
+}
+
 }  // namespace
 
 extern "C" {
+
+#if SCCBF_HAS_BATCHES
+int sccbf_solve_batches_f32(const sccbf_params* p, int32_t K, int32_t M, int64_t A_max, const sccbf_batch* batches,
+                            void* stream)
+{
+    return solve_batches_impl<float>(p, K, M, A_max, batches, stream);
+}
+
+int sccbf_solve_batches_f64(const sccbf_params* p, int32_t K, int32_t M, int64_t A_max, const sccbf_batch* batches,
+                            void* stream)
+{
+    return solve_batches_impl<double>(p, K, M, A_max, batches, stream);
+}
+#endif
 
 #if SCCBF_HAS_F32
 int sccbf_ingest_bbox_f32(int64_t A, int32_t M, const float* bbox, const uint8_t* kind, double buffer,

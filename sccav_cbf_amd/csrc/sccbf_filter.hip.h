@@ -338,18 +338,20 @@ template <typename T> __host__ __device__ inline size_t wave_lds_bytes(int M, in
 // turn, so the two sit on the same XCD, start about together, and the second finds the line in that XCD's L2.
 // (Placement is not promised: if it differs, the line is fetched twice and nothing else changes.)  The grid
 // is a multiple of 16 workgroups.
-template <int QPB, bool PAIRED> __device__ inline long long wave_first_agent()
+template <int QPB, bool PAIRED> __device__ inline long long wave_first_agent(unsigned block = blockIdx.x)
 {
-    if (!PAIRED) return (long long)blockIdx.x * QPB;
-    const unsigned xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+    if (!PAIRED) return (long long)block * QPB;
+    const unsigned xcd = block & 7u, slot = block >> 3;
     return ((long long)(slot >> 1) * 8 + xcd) * (2 * QPB) + (slot & 1u) * QPB;
 }
 
-template <typename T, int QPB, bool QP_ONLY, int G, bool PAIRED = false>
-__global__ __launch_bounds__(QPB * G) void k_wave(const KArgs<T> p)
+// The work of one workgroup on the QPB agents from wave_first_agent(block) on; smem_raw: the workgroup's dynamic
+// LDS.  A workgroup may call it again for another `block`: the tables it reads after its last barrier
+// (answer, status) are rewritten only after the next call's second barrier.
+template <typename T, int QPB, bool QP_ONLY, int G, bool PAIRED>
+__device__ inline void wave_body_(const KArgs<T>& p, unsigned block, unsigned char* smem_raw)
 {
     using v4 = typename VT<T>::v4;
-    extern __shared__ __align__(16) unsigned char smem_raw[];
     static_assert(QPB * G % 64 == 0, "whole wavefronts");
     constexpr int RS = G;  // rows of an agent formed side by side
     const int M = p.M;
@@ -358,7 +360,7 @@ __global__ __launch_bounds__(QPB * G) void k_wave(const KArgs<T> p)
     const int qa = (int)(threadIdx.x % QPB), rsub = (int)(threadIdx.x / QPB);  // forming rows
     const int qs = (int)(threadIdx.x / G), g = (int)(threadIdx.x % G);         // solving
 
-    long long qp = wave_first_agent<QPB, PAIRED>() + qa;
+    long long qp = wave_first_agent<QPB, PAIRED>(block) + qa;
     const bool live = qp < p.A;
     if (!live) qp = p.A - 1;  // the thread stays for the barriers; its stores are masked
     if (threadIdx.x < QPB) tab.bad[threadIdx.x] = 0;
@@ -400,6 +402,13 @@ __global__ __launch_bounds__(QPB * G) void k_wave(const KArgs<T> p)
     __syncthreads();
     if (rsub == 0 && live)
         store_result_(p, qp, QP_ONLY, tab.status[qa], tab.answer[2 * qa], tab.answer[2 * qa + 1], e, ur0, ur1);
+}
+
+template <typename T, int QPB, bool QP_ONLY, int G, bool PAIRED = false>
+__global__ __launch_bounds__(QPB * G) void k_wave(const KArgs<T> p)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    wave_body_<T, QPB, QP_ONLY, G, PAIRED>(p, blockIdx.x, smem_raw);
 }
 
 // ------------------------------------- barrier value and partials only (no rows, no QP)

@@ -198,3 +198,27 @@ def test_no_cpu_fallback_in_front_end():
         BatchedNominal().control(z, torch.zeros((3, 4)), torch.zeros((1,), dtype=torch.int32))
     with pytest.raises(_lib.SccbfError):
         vehicle_step(z, torch.zeros((1, 2)))
+
+
+def test_batches_argument_validation(lib):
+    assert C.sizeof(_lib.Batch) == 64
+    p = _lib.Params()
+    lib.sccbf_default_params(C.byref(p))
+    nul = C.c_void_p(0)
+    for fn in (lib.sccbf_solve_batches_f32, lib.sccbf_solve_batches_f64):
+        assert fn(None, 1, 16, 64, nul, None) == -1                      # no params
+        assert fn(C.byref(p), -1, 16, 64, nul, None) == -1               # negative count
+        assert fn(C.byref(p), _lib.MAX_BATCHES + 1, 16, 64, nul, None) == -1
+        assert fn(C.byref(p), 4, 16, -1, nul, None) == -1
+        assert fn(C.byref(p), 4, 16, 1 << 31, nul, None) == -1           # beyond the kernels' index range
+        assert fn(C.byref(p), 4, _lib.MAX_ROWS + 1, 64, nul, None) == -2
+        assert fn(C.byref(p), 0, 16, 64, nul, None) == 0                 # no batches: nothing to do
+        assert fn(C.byref(p), 4, 16, 0, nul, None) == 0                  # no agents: nothing to do
+        assert fn(C.byref(p), 4, 16, 64, nul, None) == -1                # no table
+        for dyn in (_lib.DYN_DUM, _lib.DYN_SADBM):                       # the models that take more than these arrays
+            p.dynamics = dyn
+            assert fn(C.byref(p), 0, 16, 64, nul, None) == -1
+        p.dynamics = 0
+        p.flags = _lib.FLAG_CONE_BETA_STATE
+        assert fn(C.byref(p), 0, 16, 64, nul, None) == -1
+        p.flags = 0
