@@ -123,6 +123,7 @@ extern "C" {
 #define SCCBF_ERR_LAUNCH (-4)      /* hipLaunch failed */
 #define SCCBF_ERR_VARIANT (-5)     /* lanes_per_qp cannot hold M rows */
 #define SCCBF_ERR_NO_DEVICE (-6)   /* no HIP device / wrong architecture */
+#define SCCBF_ERR_BATCHES (-7)     /* more batches than SCCBF_MAX_STATIC_BATCHES */
 
 #define SCCBF_MAX_ROWS 1024
 
@@ -215,6 +216,28 @@ int sccbf_solve_batches_f32(const sccbf_params* p, int32_t K, int32_t M, int64_t
                             const sccbf_batch* batches, void* stream);
 int sccbf_solve_batches_f64(const sccbf_params* p, int32_t K, int32_t M, int64_t A_max,
                             const sccbf_batch* batches, void* stream);
+
+/*
+ * sccbf_solve_batches_* for callers that cannot allocate device memory for the table of records: code under
+ * HIP graph capture, a tight serving loop, a harness that forbids hipMalloc.  No counterpart in the reference
+ * (which has no device at all); same kernels and same answers as sccbf_solve_batches_*.
+ *   batches       HOST array of K records (read during the call, the caller may reuse it at once); their
+ *                 pointers are device pointers as everywhere.  Being host memory, the records are checked
+ *                 here: A < 0, A >= 2^31 or a required pointer missing is SCCBF_ERR_ARG for the whole call.
+ *   scalar_bytes  4: the arrays are float (as sccbf_solve_batches_f32), 8: double
+ *   K             at most SCCBF_MAX_STATIC_BATCHES, else SCCBF_ERR_BATCHES
+ * The records are staged in a table that the library itself holds in device memory: a file-scope array of
+ * SCCBF_MAX_STATIC_BATCHES records (64 KB) on every GPU the library runs on, for the life of the process.  The
+ * call allocates and frees nothing: it launches small kernels that write the records (passed as kernel
+ * arguments) into the table, then the filter, all on `stream`.
+ * All calls on one GPU share that table: calls on the same stream follow each other safely; calls whose launches
+ * may overlap (different streams, or several host threads) race on it and must be serialised by the caller, or
+ * use sccbf_solve_batches_* with tables of their own.  The first call on a device looks up the table's address
+ * (hipGetSymbolAddress): make that call outside stream capture.
+ */
+#define SCCBF_MAX_STATIC_BATCHES 1024
+int sccbf_solve_batches_static(const sccbf_params* p, int32_t scalar_bytes, int32_t K, int32_t M,
+                               const sccbf_batch* batches, void* stream);
 
 /*
  * Steer-rate model: SADBM_CBF_2DS.solve_cbf, reference cbf/cbf.py:349-437, for A agents.

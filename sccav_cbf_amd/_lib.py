@@ -20,6 +20,7 @@ FLAG_CONE_BETA_STATE = 16
 FLAG_OBS_STREAMED = 32
 MAX_ROWS = 1024
 ERR_ARG, ERR_ROWS, ERR_WEIGHT, ERR_LAUNCH, ERR_VARIANT, ERR_NO_DEVICE = -1, -2, -3, -4, -5, -6
+ERR_BATCHES = -7
 
 EXPORTS = ("sccbf_version", "sccbf_strerror", "sccbf_default_params", "sccbf_solve_f32",
            "sccbf_solve_f64", "sccbf_qp_f32", "sccbf_qp_f64", "sccbf_partials_f32",
@@ -29,7 +30,8 @@ EXPORTS = ("sccbf_version", "sccbf_strerror", "sccbf_default_params", "sccbf_sol
            "sccbf_solve_sa_f32", "sccbf_solve_sa_f64", "sccbf_ingest_bbox_f32", "sccbf_ingest_bbox_f64",
            "sccbf_lane_fit_f32", "sccbf_lane_fit_f64", "sccbf_solve_step_f32", "sccbf_solve_step_f64",
            "sccbf_prepare_obs_f32", "sccbf_prepare_obs_f64", "sccbf_vehicle_step_kin_f32",
-           "sccbf_vehicle_step_kin_f64", "sccbf_solve_batches_f32", "sccbf_solve_batches_f64")
+           "sccbf_vehicle_step_kin_f64", "sccbf_solve_batches_f32", "sccbf_solve_batches_f64",
+           "sccbf_solve_batches_static")
 MOTION_STATIC, MOTION_CONSTANT_VELOCITY, MOTION_SEEKER = 0, 1, 2
 STEP_KIN_ACC, STEP_KIN_VEL, STEP_UNICYCLE = 0, 1, 2
 NOMINAL_WAYPOINT_SPEED = 1
@@ -62,6 +64,7 @@ class Batch(C.Structure):
 
 
 MAX_BATCHES = 65535
+MAX_STATIC_BATCHES = 1024
 
 
 class SccbfError(RuntimeError):
@@ -164,10 +167,13 @@ def _bind(L):
         f = getattr(L, name)
         f.restype = C.c_int
         f.argtypes = [C.c_int64, vp, vp, C.c_int32, C.c_double, C.c_double, C.c_double, vp]
-    for name in ("sccbf_solve_batches_f32", "sccbf_solve_batches_f64"):
+    for name in ("sccbf_solve_batches_f32", "sccbf_solve_batches_f64",
+           "sccbf_solve_batches_static"):
         f = getattr(L, name)
         f.restype = C.c_int
         f.argtypes = [C.POINTER(Params), C.c_int32, C.c_int32, C.c_int64, vp, vp]
+    L.sccbf_solve_batches_static.restype = C.c_int
+    L.sccbf_solve_batches_static.argtypes = [C.POINTER(Params), C.c_int32, C.c_int32, C.c_int32, vp, vp]
     _lib = L
     return L
 

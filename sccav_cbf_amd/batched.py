@@ -170,6 +170,23 @@ class BatchedCBF:
                     C.c_void_p(table.records.data_ptr() + 64 * first), C.c_void_p(stream))
         _lib.check(rc)
 
+    def solve_batches_static(self, table, first=0, count=None):
+        """solve_batches() without a record table in device memory of the caller's: the records go to the
+        library's own table on the GPU (sccbf_solve_batches_static; at most _lib.MAX_STATIC_BATCHES batches per
+        call, nothing is allocated).  `table` is a BatchTable, of which only the host copy of the records is used.
+        Calls on one GPU share the library's table: keep them on one stream, or serialise them."""
+        K = len(table) - first if count is None else int(count)
+        if first < 0 or K < 0 or first + K > len(table):
+            raise ValueError("batches %d ... %d of a table of %d" % (first, first + K, len(table)))
+        self.params.flags = (table.flags | (FLAG_SLIP_IO if self.slip_io else 0)
+                             | (_lib.FLAG_OBS_STREAMED if self.streamed_obs else 0))
+        rec = np.ascontiguousarray(table.host_records[first:first + K])
+        with torch.cuda.device(table.device):
+            stream = torch.cuda.current_stream(table.device).cuda_stream
+            rc = self._lib.sccbf_solve_batches_static(C.byref(self.params), 4 if table.dtype == torch.float32 else 8,
+                                                      K, table.M, C.c_void_p(rec.ctypes.data), C.c_void_p(stream))
+        _lib.check(rc)
+
     def prepare_obs(self, obs, obs_type, agents=None):
         """As-written ellipse / cone slots -> their prepared kinds, in place: the module's prepare_obs()."""
         return prepare_obs(obs, obs_type, agents)

@@ -731,6 +731,77 @@ int solve_batches_impl(const sccbf_params* sp, int32_t K, int32_t M, int64_t a_m
     return batches_launch<T>(sp, K, M, a_max, table, stream);
 }
 
+#if SCCBF_HAS_BATCHES
+// ------------------------------------------- the batch table kept by the library (sccbf_solve_batches_static)
+// Every GPU the library runs on holds its own copy of this array, at its own address, until the process ends.
+// In host code the name is only a handle: the address comes from hipGetSymbolAddress, once per device.
+static __device__ __align__(256) sccbf_batch scratch[SCCBF_MAX_STATIC_BATCHES];
+
+sccbf_batch* static_table_()
+{
+    static std::atomic<sccbf_batch*> table[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    sccbf_batch* t = table[dev].load(std::memory_order_acquire);
+    if (!t) {
+        void* q = nullptr;
+        if (hipGetSymbolAddress(&q, HIP_SYMBOL(scratch)) != hipSuccess || !q) return nullptr;
+        t = static_cast<sccbf_batch*>(q);
+        table[dev].store(t, std::memory_order_release);
+    }
+    return t;
+}
+
+// Records travel to the table as kernel arguments (2 KB per launch): no copy engine, no staging buffer, nothing
+// that waits for the stream; the fill is ordered on the stream like the launch that reads the table.
+constexpr int kFillBatches = 32;
+struct BatchChunk {
+    sccbf_batch b[kFillBatches];
+};
+__global__ __launch_bounds__(kFillBatches * 8) void k_table_fill(sccbf_batch* dst, const BatchChunk c, int n)
+{
+    const int i = (int)threadIdx.x;  // one 8-byte field each
+    if (i >= n * 8) return;
+    const sccbf_batch& r = c.b[i / 8];
+    const unsigned long long f[8] = {(unsigned long long)r.A,
+                                     (unsigned long long)r.state, (unsigned long long)r.u_ref,
+                                     (unsigned long long)r.obs, (unsigned long long)r.obs_type,
+                                     (unsigned long long)r.u_out, (unsigned long long)r.status,
+                                     (unsigned long long)r.rows_out};
+    reinterpret_cast<unsigned long long*>(dst)[i] = f[i % 8];
+}
+
+template <typename T>
+int solve_batches_static_impl(const sccbf_params* sp, int32_t K, int32_t M, const sccbf_batch* host, void* stream)
+{
+    if (K < 0) return SCCBF_ERR_ARG;
+    if (K > SCCBF_MAX_STATIC_BATCHES) return SCCBF_ERR_BATCHES;
+    if (K > 0 && !host) return SCCBF_ERR_ARG;
+    int64_t a_max = 0;
+    for (int i = 0; i < K; ++i) {  // the records are host memory here: everything the kernel would skip is refused
+        const sccbf_batch& r = host[i];
+        if (r.A < 0 || r.A > 0x7fffffffLL) return SCCBF_ERR_ARG;
+        if (r.A > 0 && (!r.state || !r.u_ref || !r.u_out || !r.status)) return SCCBF_ERR_ARG;
+        if (r.A > 0 && M > 0 && (!r.obs || !r.obs_type)) return SCCBF_ERR_ARG;
+        a_max = r.A > a_max ? r.A : a_max;
+    }
+    // arguments first: a call that is going to be refused must not touch the table
+    int rc = batches_launch<T>(sp, 0, M, a_max, nullptr, stream);
+    if (rc != SCCBF_OK || K == 0 || a_max == 0) return rc;
+    sccbf_batch* table = static_table_();
+    if (!table) return SCCBF_ERR_NO_DEVICE;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    for (int at = 0; at < K; at += kFillBatches) {
+        BatchChunk c;
+        const int n = K - at < kFillBatches ? K - at : kFillBatches;
+        for (int i = 0; i < kFillBatches; ++i) c.b[i] = host[at + (i < n ? i : 0)];
+        hipLaunchKernelGGL(k_table_fill, dim3(1), dim3(kFillBatches * 8), 0, s, table + at, c, n);
+        if (hipGetLastError() != hipSuccess) return SCCBF_ERR_LAUNCH;
+    }
+    return batches_launch<T>(sp, K, M, a_max, table, stream);
+}
+#endif
+
 }  // namespace
 
 extern "C" {
@@ -746,6 +817,15 @@ int sccbf_solve_batches_f64(const sccbf_params* p, int32_t K, int32_t M, int64_t
                             void* stream)
 {
     return solve_batches_impl<double>(p, K, M, A_max, batches, stream);
+}
+
+int sccbf_solve_batches_static(const sccbf_params* p, int32_t scalar_bytes, int32_t K, int32_t M,
+                               const sccbf_batch* batches, void* stream)
+{
+    forget_earlier_errors_();
+    if (scalar_bytes == 4) return solve_batches_static_impl<float>(p, K, M, batches, stream);
+    if (scalar_bytes == 8) return solve_batches_static_impl<double>(p, K, M, batches, stream);
+    return SCCBF_ERR_ARG;
 }
 #endif
 
@@ -830,6 +910,7 @@ const char* sccbf_strerror(int code)
     case SCCBF_ERR_LAUNCH: return "kernel launch failed";
     case SCCBF_ERR_VARIANT: return "lanes_per_qp cannot hold M rows or is not offered for this model (use 0)";
     case SCCBF_ERR_NO_DEVICE: return "no usable HIP device";
+    case SCCBF_ERR_BATCHES: return "more batches than the library's own table holds (SCCBF_MAX_STATIC_BATCHES)";
     default: return "unknown error";
     }
 }

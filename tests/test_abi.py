@@ -34,7 +34,7 @@ def test_every_declared_symbol_is_exported(lib):
 def test_version_and_strerror(lib):
     assert lib.sccbf_version() == _lib.ABI_VERSION
     assert lib.sccbf_strerror(0) == b"ok"
-    for code in range(-6, 0):
+    for code in range(-7, 0):
         assert len(lib.sccbf_strerror(code)) > 3
     assert lib.sccbf_strerror(-99) == b"unknown error"
 
@@ -222,3 +222,28 @@ def test_batches_argument_validation(lib):
         p.flags = _lib.FLAG_CONE_BETA_STATE
         assert fn(C.byref(p), 0, 16, 64, nul, None) == -1
         p.flags = 0
+
+
+def test_static_batches_argument_validation(lib):
+    p = _lib.Params()
+    lib.sccbf_default_params(C.byref(p))
+    nul = C.c_void_p(0)
+    fn = lib.sccbf_solve_batches_static
+    recs = (_lib.Batch * 3)()
+    assert fn(C.byref(p), 2, 1, 16, recs, None) == -1                    # neither float nor double
+    assert fn(None, 4, 1, 16, recs, None) == -1
+    assert fn(C.byref(p), 4, -1, 16, recs, None) == -1
+    assert fn(C.byref(p), 4, _lib.MAX_STATIC_BATCHES + 1, 16, recs, None) == _lib.ERR_BATCHES
+    assert fn(C.byref(p), 8, 3, 16, nul, None) == -1                     # no records
+    assert fn(C.byref(p), 8, 0, 16, nul, None) == 0                      # no batches: nothing to do
+    assert fn(C.byref(p), 8, 3, 16, recs, None) == 0                     # three empty batches: nothing to do
+    assert fn(C.byref(p), 8, 3, _lib.MAX_ROWS + 1, recs, None) == -2
+    recs[1].A = 8                                                        # agents without arrays
+    assert fn(C.byref(p), 4, 3, 16, recs, None) == -1
+    recs[1].A = -1
+    assert fn(C.byref(p), 4, 3, 16, recs, None) == -1
+    recs[1].A = 1 << 31
+    assert fn(C.byref(p), 4, 3, 16, recs, None) == -1
+    recs[1].A = 0
+    p.dynamics = _lib.DYN_DUM
+    assert fn(C.byref(p), 4, 3, 16, recs, None) == -1
