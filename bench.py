@@ -1,21 +1,25 @@
 #!/usr/bin/env python3
 """Benchmark of the batched CBF-QP safety filter on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--scaling weak|strong]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A step = one control tick (barrier rows + 2-input QP) for one batch of 65536 agents x
-16 obstacle slots (8 ellipse + 8 collision cone, fp32) per GPU.  Inputs are resident in
-HBM before the timed region; the steps walk a ring of distinct batches larger than the
-256 MiB Infinity Cache so every step streams its inputs from HBM.  Ranks hold independent
-batches (weak scaling, no data-path collective).  Rank 0 prints ONE JSON line.
-Order: untimed clock ramp (--ramp-ms of work, an idle GPU is slow for its first milliseconds),
-W untimed warm-up steps, barrier, exactly K timed steps, barrier.
+A step = one control tick (barrier rows + 2-input QP) for one batch of 65536 agents x 16 obstacle slots
+(8 ellipse + 8 collision cone, fp32).  Inputs are resident in HBM before the timed region; the steps walk a
+ring of 20 distinct batches (718 MB, more than twice the 256 MiB Infinity Cache), so every step streams its
+inputs from HBM.  The steps are independent batches (a Monte-Carlo sweep: every step has its own inputs and
+outputs), and the timed region hands them to the library twenty at a time: ONE launch of
+sccbf_solve_batches_f32 over twenty batch records (the answers of twenty sccbf_solve_f32 launches, bit for bit).
+--scaling weak (default): every rank owns a full ring of 65536-agent batches; strong: ONE 65536-agent batch per
+step, every rank solves its contiguous block of 65536 / N agents (BASELINE's configuration 4 as stated).  Either
+way the solve has no collective.  Rank 0 prints ONE JSON line.
+Order: untimed clock ramp (--ramp-ms of work, an idle GPU is slow for its first milliseconds), W untimed
+warm-up steps, barrier, exactly K timed steps, barrier.
 
---gpus N with N > 1 and no WORLD_SIZE in the environment: this process touches no GPU, starts N
-fresh rank processes (one per GPU, RCCL through torch.distributed "nccl") and relays rank 0's
-line; it exits non-zero if fewer than N devices are visible or any rank fails.  Under a launcher
-that sets WORLD_SIZE (torch.distributed.run) the process is a rank and --gpus must equal WORLD_SIZE.
+--gpus N with N > 1 and no WORLD_SIZE in the environment: this process touches no GPU, starts N fresh rank
+processes (one per GPU, RCCL through torch.distributed "nccl") and relays rank 0's line; it exits non-zero if
+fewer than N devices are visible or any rank fails.  Under a launcher that sets WORLD_SIZE
+(torch.distributed.run) the process is a rank and --gpus must equal WORLD_SIZE.
 """
 import argparse
 import json
@@ -35,13 +39,17 @@ from sccav_cbf_amd import scenarios  # noqa: E402
 
 AGENTS = 65536
 ROWS = 16
-RING = 10                     # distinct batches: 10 x 35.9 MB > 256 MiB
+RING = 20                     # distinct batches = batches per launch: 20 x 35.9 MB = 718 MB
 HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E peak
 
 
 def algorithmic_bytes(A, M, w=4):
     # per QP: state 4 + u_ref 2 + 8 M obstacle scalars + u_out 2, plus the int32 status
     return A * (w * (4 + 2 + 8 * M + 2) + 4)
+
+
+def frac_of_peak(nbytes, ms):
+    return nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS
 
 
 def c4_batch(agents, seed, slots):
@@ -52,31 +60,53 @@ def c4_batch(agents, seed, slots):
     return scenarios.prepared(w) if slots == "prepared" else w
 
 
-def make_ring(rank, device, n, agents=AGENTS, layout="tiles", slots="prepared"):
+def to_device(w, device, dtype=torch.float32, layout="tiles", lo=0, hi=None):
+    """Host batch (or the agents [lo, hi) of it) -> device tensors with outputs."""
     from sccav_cbf_amd.batched import planes_to_tiled
+    hi = w["state"].shape[0] if hi is None else hi
+    n = hi - lo
+    t = dict(state=torch.from_numpy(np.ascontiguousarray(w["state"][lo:hi])).to(device).to(dtype),
+             u_ref=torch.from_numpy(np.ascontiguousarray(w["u_ref"][lo:hi])).to(device).to(dtype),
+             obs=torch.from_numpy(np.ascontiguousarray(w["obs"][:, :, lo:hi])).to(device).to(dtype),
+             obs_type=torch.from_numpy(w["obs_type"]).to(device),
+             u_out=torch.empty((n, 2), dtype=dtype, device=device),
+             status=torch.empty((n,), dtype=torch.int32, device=device))
+    if layout == "tiles":   # tiles of 64 agents: (A/64, M, 2, 64, 4)
+        t["obs"] = planes_to_tiled(t["obs"])
+    return t
+
+
+def make_ring(seed0, device, n, agents=AGENTS, layout="tiles", slots="prepared", lo=0, hi=None):
+    return [to_device(c4_batch(agents, seed0 + b, slots), device, layout=layout, lo=lo, hi=hi) for b in range(n)]
+
+
+def rotated_ring(w, device, n, dtype, stride, layout="tiles"):
+    """n batches made of one by rotating its agents by whole tiles: distinct addresses, the same answers."""
     ring = []
     for b in range(n):
-        w = c4_batch(agents, 1234 + 4 + 1000 * rank + b, slots)
-        t = dict(state=torch.from_numpy(w["state"]).float().to(device),
-                 u_ref=torch.from_numpy(w["u_ref"]).float().to(device),
-                 obs=torch.from_numpy(w["obs"]).float().to(device),   # (M,2,A,4) planes
-                 obs_type=torch.from_numpy(w["obs_type"]).to(device),
-                 u_out=torch.empty((agents, 2), dtype=torch.float32, device=device),
-                 status=torch.empty((agents,), dtype=torch.int32, device=device))
-        if layout == "tiles":   # tiles of 64 agents: (A/64, M, 2, 64, 4)
-            t["obs"] = planes_to_tiled(t["obs"])
-        ring.append(t)
+        sh = 64 * stride * (b + 1)
+        r = dict(state=np.roll(w["state"], sh, axis=0), u_ref=np.roll(w["u_ref"], sh, axis=0),
+                 obs=np.roll(w["obs"], sh, axis=2), obs_type=w["obs_type"])
+        ring.append(to_device(r, device, dtype=dtype, layout=layout))
     return ring
 
 
-def cpu_baseline(seconds=10.0):
-    """The fp64 oracle on the host cores, on the first batch of the ring: OpenMP on the threads this
-    process may use (OMP_NUM_THREADS where the box sets it, else every core), and one thread."""
+def shard_views(ring, n):
+    """The first n agents (whole tiles) of every batch of a tiled ring, as views: no new memory."""
+    return [dict(state=b["state"][:n], u_ref=b["u_ref"][:n], obs=b["obs"][:n // 64], obs_type=b["obs_type"],
+                 u_out=b["u_out"][:n], status=b["status"][:n]) for b in ring]
+
+
+# ------------------------------------------------------------------------------ CPU baseline
+def cpu_baseline(seconds=10.0, slots="prepared"):
+    """The fp64 oracle on the host cores, on the first batch of the ring (the same slot kinds the GPU reads):
+    OpenMP on the threads this process may use (OMP_NUM_THREADS where the box sets it, else every core), and
+    one thread."""
     from oracle import oracle as orc
     orc.build()
     host_cores = os.cpu_count() or 1
     threads = int(os.environ.get("OMP_NUM_THREADS", host_cores))
-    w = scenarios.config4(A=AGENTS, seed=1234 + 4)
+    w = c4_batch(AGENTS, 1234 + 4, slots)
     p = orc.make_params(alpha=1.0, R=(0.5, 0, 0, 0.5))
     omp = orc.lib()   # liboracle.so links libgomp: its symbols resolve through the same handle
 
@@ -98,8 +128,8 @@ def cpu_baseline(seconds=10.0):
     out = {"value": v, "unit": "solves/s", "cores": threads, "threads": threads, "host_cores": host_cores,
            "value_1thread": v1, "kind": "port",
            "sample": "%d passes of the fp64 C oracle (OpenMP, %d threads of %d host cores) over one "
-                     "65536-agent x 16-row batch, %.1f s; one thread: %d passes over 8192 agents, %.1f s"
-                     % (n, threads, host_cores, dt, n1, dt1)}
+                     "65536-agent x 16-row batch (%s slots), %.1f s; one thread: %d passes over 8192 agents, %.1f s"
+                     % (n, threads, host_cores, slots, dt, n1, dt1)}
     # the reference hands every QP to an interpreted general-purpose solver (cvxopt.solvers.cp,
     # cbf/cbf.py:213); cvxopt is not installed here, so scipy's SLSQP on the same rows stands in
     try:
@@ -132,152 +162,200 @@ def slsqp_proxy(orc, p, w, n_qp=192, budget=6.0):
             "sample": "%d QPs, %.1f s" % (done, dt)}
 
 
+# ------------------------------------------------------------------------------ timing helpers
 def _profile_json(name):
-    """A number kept from a counter run of this same workload (profiles/*.json), or None."""
-    path = os.path.join(ROOT, "profiles", name)
+    """HBM bytes per launch kept from a counter run of this same workload (profiles/*.json), or None when there is
+    none or when it was taken on other sources than the library that is loaded now."""
+    from sccav_cbf_amd import _build
     try:
-        return json.load(open(path)).get("hbm_bytes_per_launch")
+        d = json.load(open(os.path.join(ROOT, "profiles", name)))
+        return d.get("hbm_bytes_per_launch") if d.get("source_hash") == _build.source_hash() else None
     except Exception:
         return None
 
 
-def _time_graph(walk, stream, n_per_walk, reps, graph=True, branches=1):
-    """ms per launch of walk() (n_per_walk launches) replayed from a hipGraph on `stream` (or launched
-    eagerly, graph=False: a profiler then sees every launch).  walk may be a list of n_per_walk independent
-    launches instead: with branches > 1 they are dealt to that many parallel branches of the graph."""
-    steps = walk if isinstance(walk, (list, tuple)) else None
-    if steps is not None:
-        def walk():
-            for f in steps:
-                f()
-    walk()
-    torch.cuda.synchronize()
-
-    class _Eager:
-        replay = staticmethod(walk)
-    g = _Eager
-    if graph:
-        from sccav_cbf_amd.batched import capture_independent
-        g = capture_independent(steps if steps is not None else [walk], branches if steps is not None else 1, stream)
-    for _ in range(reps):   # the GPU idled while the host built the batch: let the clocks come back
-        g.replay()
+def _events_ms(fn, stream, reps, warm=None):
+    """Device milliseconds per call of fn() (HIP events on `stream`), after `warm` untimed calls."""
+    for _ in range(reps // 4 + 2 if warm is None else warm):
+        fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(stream)
     for _ in range(reps):
-        g.replay()
+        fn()
     e1.record(stream)
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / (reps * n_per_walk)   # ms per launch
+    return e0.elapsed_time(e1) / reps
 
 
+def _time_graph(steps, stream, reps, branches=1, graph=True):
+    """ms per launch of the independent launches `steps` replayed from a hipGraph on `stream` (dealt to that many
+    parallel branches), or launched eagerly (graph=False: a profiler then sees every launch)."""
+    def walk():
+        for f in steps:
+            f()
+    walk()
+    torch.cuda.synchronize()
+    fn = walk
+    if graph:
+        from sccav_cbf_amd.batched import capture_independent
+        fn = capture_independent(steps, branches, stream).replay
+    return _events_ms(fn, stream, reps, warm=reps) / len(steps)
+
+
+def _solve_fn(flt, b, ty=None):
+    ty = b["obs_type"] if ty is None else ty
+    return lambda: flt.solve(b["state"], b["u_ref"], b["obs"], ty, u_out=b["u_out"], status=b["status"])
+
+
+def _line(A, M, ms, w=4, **kw):
+    ab = algorithmic_bytes(A, M, w)
+    d = {"us_per_step": ms * 1e3, "solves_per_s": A / (ms * 1e-3), "frac": frac_of_peak(ab, ms)}
+    d.update(kw)
+    return d
+
+
+def fused_and_single(flt, ring, stream, reps_fused=60, reps_single=20):
+    """The ring's batches as ONE launch (sccbf_solve_batches_*) and one launch at a time (a serial hipGraph of
+    sccbf_solve_* launches): ms per batch each."""
+    from sccav_cbf_amd.batched import BatchTable
+    table = BatchTable(ring)
+    fused = _events_ms(lambda: flt.solve_batches(table), stream, reps_fused) / len(ring)
+    single = _time_graph([_solve_fn(flt, b) for b in ring], stream, reps_single)
+    return fused, single
+
+
+def _filter(lanes=0, alpha=1.0, streamed=True, **kw):
+    from sccav_cbf_amd.batched import BatchedCBF
+    return BatchedCBF(alpha=alpha, lr=1.45, lf=1.45, R=np.diag([0.5, 0.5]), lanes_per_qp=lanes, streamed_obs=streamed, **kw)
+
+
+# ------------------------------------------------------------------------------ sections beside the headline (N = 1)
 def large_batch(flt, device, layout, slots, agents=1 << 20, n=3, reps=200, graph=True):
-    """The same kernel on 2^20 agents per launch (not part of `value`): at that size a launch is
-    no longer dominated by its start-up and tail.  The ring re-uses one C4 batch rotated by whole
-    tiles: 3 x 575 MB, more than twice the Infinity Cache."""
-    from sccav_cbf_amd.batched import planes_to_tiled
-    w = c4_batch(agents, 99, slots)
-    ring = []
-    for b in range(n):
-        sh = 64 * 1237 * (b + 1)
-        obs = torch.from_numpy(np.roll(w["obs"], sh, axis=2)).float().to(device)
-        ring.append(dict(
-            state=torch.from_numpy(np.roll(w["state"], sh, axis=0)).float().to(device),
-            u_ref=torch.from_numpy(np.roll(w["u_ref"], sh, axis=0)).float().to(device),
-            obs=planes_to_tiled(obs) if layout == "tiles" else obs,
-            u_out=torch.empty((agents, 2), dtype=torch.float32, device=device),
-            status=torch.empty((agents,), dtype=torch.int32, device=device)))
-    ty = torch.from_numpy(w["obs_type"]).to(device)
+    """The same kernel on 2^20 agents in ONE sccbf_solve_f32 launch (not part of `value`).  The ring re-uses one C4
+    batch rotated by whole tiles: 3 x 575 MB, more than twice the Infinity Cache."""
+    ring = rotated_ring(c4_batch(agents, 99, slots), device, n, torch.float32, 1237, layout)
     st = torch.cuda.Stream(device)
     with torch.cuda.stream(st):
-        def launch(b):
-            return lambda: flt.solve(b["state"], b["u_ref"], b["obs"], ty, u_out=b["u_out"], status=b["status"])
-        steps = [launch(b) for b in ring]
-        ms = _time_graph(steps, st, n, reps, graph=graph)
+        ms = _time_graph([_solve_fn(flt, b) for b in ring], st, reps, graph=graph)
     ab = algorithmic_bytes(agents, ROWS)
-    out = {"agents": agents, "kernel_ms": ms, "solves_per_s": agents / (ms * 1e-3),
-           "achieved_GBps": ab / (ms * 1e-3) / 1e9, "frac": ab / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-           "algorithmic_bytes_per_launch": ab, "traffic": _profile_json("traffic_large.json"),
-           "launches": reps * n,
-           # (three overlapping launches of this size measured slower: 95.7 us per launch)
-           "launch": "one at a time (serial hipGraph)" if graph else "eager"}
+    return {"agents": agents, "kernel_ms": ms, "solves_per_s": agents / (ms * 1e-3),
+            "achieved_GBps": ab / (ms * 1e-3) / 1e9, "frac": frac_of_peak(ab, ms),
+            "algorithmic_bytes_per_launch": ab, "traffic": _profile_json("traffic_large.json"),
+            "launches": reps * n, "launch": "one at a time (serial hipGraph)" if graph else "eager"}
+
+
+def variants_section(ring, device, stream):
+    """Lanes per QP at C4: 64 = the one-wavefront-per-QP variant, 0 = the library's choice (4 at this size)."""
+    out = {}
+    for lanes in (0, 1, 2, 4, 8, 16, 64):
+        fused, single = fused_and_single(_filter(lanes), ring, stream, reps_fused=20 if lanes < 64 else 6,
+                                         reps_single=8 if lanes < 64 else 3)
+        out["lanes_%d" % lanes if lanes else "auto"] = {
+            "twenty_batches_per_launch": _line(AGENTS, ROWS, fused), "one_launch_per_step": _line(AGENTS, ROWS, single)}
+    out["note"] = ("lanes per QP (sccbf_params.lanes_per_qp): 1-16 keep the rows in registers, 64 = one wavefront per QP with the "
+                   "rows in LDS only; same answers")
     return out
 
 
-def fp64_lines(device):
-    """The reference computes in fp64 throughout: the same filter in fp64 on the two fp64 shapes the
-    configurations name, priced like the fp32 line (68 + 64 M bytes per QP).
-    c5: 16384 agents x (2 lanes + 6 cones), ring of 30 rotations of one batch (> 256 MiB);
-    c2: 1 ego x 32 radial obstacles, one wavefront for the QP: a launch-latency case."""
-    from sccav_cbf_amd.batched import BatchedCBF, planes_to_tiled
+def configs_section(device, c4_f32):
+    """Every configuration of the baseline in one object: microseconds per step, solves/s, share of 8 TB/s."""
+    from sccav_cbf_amd.batched import BatchedCBF, BatchTable
     out = {}
-    flt = BatchedCBF(alpha=1.0, lr=1.45, lf=1.45, R=np.diag([0.5, 0.5]))
     st = torch.cuda.Stream(device)
     with torch.cuda.stream(st):
-        A, n = 16384, 30
-        w = scenarios.lanes_and_cones(A=A)
-        M = w["obs"].shape[0]
-        ty = torch.from_numpy(w["obs_type"]).to(device)
-        ring = []
-        for b in range(n):
-            sh = 64 * 37 * (b + 1)
-            ring.append(dict(
-                state=torch.from_numpy(np.roll(w["state"], sh, axis=0)).to(device),
-                u_ref=torch.from_numpy(np.roll(w["u_ref"], sh, axis=0)).to(device),
-                obs=planes_to_tiled(torch.from_numpy(np.roll(w["obs"], sh, axis=2)).to(device)),
-                u_out=torch.empty((A, 2), dtype=torch.float64, device=device),
-                status=torch.empty((A,), dtype=torch.int32, device=device)))
-
-        def launch(b):
-            return lambda: flt.solve(b["state"], b["u_ref"], b["obs"], ty, u_out=b["u_out"], status=b["status"])
-        steps = [launch(b) for b in ring]
-        ms1 = _time_graph(steps, st, n, 40)
-        ms = _time_graph(steps, st, n, 40, branches=4)
-        ab = algorithmic_bytes(A, M, w=8)
-        out["c5"] = {"workload": "C5 fp64: %d agents x %d rows (2 lanes + 6 cones)" % (A, M), "kernel_ms": ms,
-                     "launch": "hipGraph of %d launches in 4 parallel branches (independent batches)" % n,
-                     "solves_per_s": A / (ms * 1e-3), "algorithmic_bytes_per_launch": ab,
-                     "achieved_GBps": ab / (ms * 1e-3) / 1e9, "frac": ab / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                     "one_at_a_time": {"kernel_ms": ms1, "frac": ab / (ms1 * 1e-3) / 1e9 / HBM_PEAK_GBPS}}
-        del ring
-        # the bench workload itself in the reference's precision: C4 fp64, ring of 5 batches (358 MB)
-        A4, n4 = AGENTS, 5
-        w4 = scenarios.prepared(scenarios.config4(A=A4, nominal="uniform", seed=1234 + 4))
-        ty4 = torch.from_numpy(w4["obs_type"]).to(device)
-        flt4 = BatchedCBF(alpha=1.0, lr=1.45, lf=1.45, R=np.diag([0.5, 0.5]), streamed_obs=True)
-        ring4 = []
-        for b in range(n4):
-            sh = 64 * 131 * (b + 1)
-            ring4.append(dict(
-                state=torch.from_numpy(np.roll(w4["state"], sh, axis=0)).to(device),
-                u_ref=torch.from_numpy(np.roll(w4["u_ref"], sh, axis=0)).to(device),
-                obs=planes_to_tiled(torch.from_numpy(np.roll(w4["obs"], sh, axis=2)).to(device)),
-                u_out=torch.empty((A4, 2), dtype=torch.float64, device=device),
-                status=torch.empty((A4,), dtype=torch.int32, device=device)))
-
-        def launch4(b):
-            return lambda: flt4.solve(b["state"], b["u_ref"], b["obs"], ty4, u_out=b["u_out"], status=b["status"])
-        steps4 = [launch4(b) for b in ring4] * 2
-        ms1 = _time_graph(steps4, st, 2 * n4, 40)
-        ms = _time_graph(steps4, st, 2 * n4, 40, branches=3)
-        ab = algorithmic_bytes(A4, ROWS, w=8)
-        out["c4"] = {"workload": "C4 fp64: %d agents x %d rows (the bench workload in double precision)" % (A4, ROWS),
-                     "kernel_ms": ms, "launch": "hipGraph of %d launches in 3 parallel branches" % (2 * n4),
-                     "solves_per_s": A4 / (ms * 1e-3), "algorithmic_bytes_per_launch": ab,
-                     "achieved_GBps": ab / (ms * 1e-3) / 1e9, "frac": ab / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                     "one_at_a_time": {"kernel_ms": ms1, "frac": ab / (ms1 * 1e-3) / 1e9 / HBM_PEAK_GBPS}}
-        del ring4
+        # C2: 1 ego x 32 radial seekers, fp64: one QP per launch, launch latency
         w = scenarios.radial_seekers(M=32)
-        t = {k: torch.from_numpy(v).to(device) for k, v in w.items()}
-        uo = torch.empty((1, 2), dtype=torch.float64, device=device)
-        so = torch.empty((1,), dtype=torch.int32, device=device)
+        b = to_device(w, device, dtype=torch.float64, layout="planes")
+        ms = _time_graph([_solve_fn(BatchedCBF(alpha=1.0, R=np.eye(2)), b)] * 10, st, 200)
+        out["c2"] = _line(1, 32, ms, w=8, workload="C2: 1 ego x 32 radial dynamic obstacles, fp64", dtype="f64",
+                          launch="one launch per step (serial hipGraph)",
+                          note="one QP per launch: launch latency, not bandwidth")
+        # C3: 4096 agents x 8 ellipses, fp32, nominal input from the batched Stanley + PID controller
+        w = scenarios.config3(A=4096)
+        ring = rotated_ring(w, device, 8, torch.float32, 3)
+        flt = _filter(streamed=False)
+        fused, single = fused_and_single(flt, ring, st, reps_fused=200, reps_single=100)
+        out["c3"] = _line(4096, 8, single, workload="C3: 4096 agents x 8 ellipse obstacles, fp32, Stanley nominal",
+                          dtype="f32", launch="one launch per step (serial hipGraph)",
+                          eight_batches_per_launch=_line(4096, 8, fused))
+        try:
+            out["c3"]["with_nominal_controller"] = c3_with_nominal(device, st, w, flt)
+        except Exception as e:
+            out["c3"]["with_nominal_controller"] = {"error": repr(e)}
+        # C4 in both precisions
+        out["c4"] = {"f32": c4_f32}
+        w4 = scenarios.prepared(scenarios.config4(A=AGENTS, nominal="uniform", seed=1234 + 4))
+        ring4 = rotated_ring(w4, device, 10, torch.float64, 131)
+        fused, single = fused_and_single(_filter(), ring4, st, reps_fused=40, reps_single=20)
+        out["c4"]["f64"] = _line(AGENTS, ROWS, fused, w=8, dtype="f64",
+                                 workload="C4 fp64: 65536 agents x 16 rows (the bench workload in double precision)",
+                                 launch="ten batches per launch (sccbf_solve_batches_f64)",
+                                 one_launch_per_step=_line(AGENTS, ROWS, single, w=8))
+        del ring4
+        # C5: 2 lanes + 6 cones, 16384 agents, fp32 against fp64
+        w5 = scenarios.lanes_and_cones(A=16384)
+        M5 = w5["obs"].shape[0]
+        out["c5"] = {"workload": "C5: 16384 agents x %d rows (2 lanes + 6 collision cones)" % M5}
+        for name, dt, wbytes, n in (("f32", torch.float32, 4, 60), ("f64", torch.float64, 8, 30)):
+            ring5 = rotated_ring(w5, device, n, dt, 37)
+            fused, single = fused_and_single(_filter(), ring5, st, reps_fused=40, reps_single=20)
+            out["c5"][name] = _line(16384, M5, fused, w=wbytes, launch="%d batches per launch" % n,
+                                    one_launch_per_step=_line(16384, M5, single, w=wbytes))
+            del ring5
+        sweep = {}
+        for alpha in (0.5, 1.0, 5.0):
+            res = {}
+            for name, dt in (("f32", torch.float32), ("f64", torch.float64)):
+                b = to_device(w5, device, dtype=dt, layout="planes")
+                BatchedCBF(alpha=alpha, lr=1.45, lf=1.45, R=np.diag([0.5, 0.5]), slip_io=True).solve(
+                    b["state"], b["u_ref"], b["obs"], b["obs_type"], u_out=b["u_out"], status=b["status"])
+                torch.cuda.synchronize()
+                res[name] = (b["u_out"].double().cpu().numpy(), b["status"].cpu().numpy())
+            (u32, s32), (u64, s64) = res["f32"], res["f64"]
+            both = (s32 == 0) & (s64 == 0)
+            du = np.abs(u32 - u64).max(axis=1)[both]
+            sweep["alpha_%g" % alpha] = {"max_abs_du": float(du.max()), "p999_abs_du": float(np.quantile(du, 0.999)),
+                                         "status_agreement": float((s32 == s64).mean()),
+                                         "optimal_in_both": int(both.sum())}
+        out["c5"]["fp32_vs_fp64"] = dict(sweep, note="u in QP coordinates (a, beta); agents optimal in both precisions")
+    return out
 
-        def walk2():
-            for _ in range(10):
-                flt.solve(t["state"], t["u_ref"], t["obs"], t["obs_type"], u_out=uo, status=so)
-        ms = _time_graph(walk2, st, 10, 200)
-        out["c2"] = {"workload": "C2 fp64: 1 ego x 32 radial rows", "kernel_ms": ms,
-                     "note": "launch latency, not bandwidth: one QP per launch"}
+
+def c3_with_nominal(device, st, w, flt):
+    """C3 as a control tick on the device: batched Stanley + PID on the shipped course, then the filter."""
+    from sccav_cbf_amd.nominal import BatchedNominal
+    cx, cy, cyaw = scenarios.spline_course()
+    traj = torch.from_numpy(np.stack([cx, cy, cyaw, np.full_like(cx, scenarios.TARGET_SPEED)], axis=1)).float().to(device)
+    nom = BatchedNominal(axle=2.9, k=0.5, ks=0.0, kp=1.0, target_speed=scenarios.TARGET_SPEED)
+    b = to_device(w, device)
+    A = b["state"].shape[0]
+    idx = torch.zeros((A,), dtype=torch.int32, device=device)
+
+    def tick():
+        nom.control(b["state"], traj, idx, None, u_ref=b["u_ref"])
+        flt.solve(b["state"], b["u_ref"], b["obs"], b["obs_type"], u_out=b["u_out"], status=b["status"])
+    ms = _time_graph([tick] * 10, st, 100)
+    return {"us_per_step": ms * 1e3, "solves_per_s": A / (ms * 1e-3),
+            "launch": "two launches per step (sccbf_nominal_f32, sccbf_solve_f32), serial hipGraph",
+            "course_waypoints": int(traj.shape[0])}
+
+
+def shard_section(flt, ring, stream):
+    """One GPU's share of C4 as stated (65536 agents over N GPUs): 8192, 16384 and 32768 agents per step."""
+    out = {}
+    t_full = None
+    for n in (AGENTS, 32768, 16384, 8192):
+        fused, single = fused_and_single(flt, shard_views(ring, n), stream, reps_fused=40, reps_single=20)
+        if n == AGENTS:
+            t_full = (fused, single)
+        out["%d_agents" % n] = {
+            "gpus_sharing_65536": AGENTS // n,
+            "twenty_steps_per_launch": _line(n, ROWS, fused, speedup_vs_one_gpu=t_full[0] / fused),
+            "one_launch_per_step": _line(n, ROWS, single, speedup_vs_one_gpu=t_full[1] / single)}
+    out["note"] = ("expected strong scaling of C4 from one GPU's own measurements: time per step of a 65536 / N-agent shard "
+                   "against the full batch; a launch of 8192 agents is bound by launch latency, twenty such steps in one "
+                   "launch are not")
     return out
 
 
@@ -298,8 +376,11 @@ def launcher(args, argv):
             print("bench.py: --gpus %d asked for, %d GPU(s) visible: not running a smaller job under that "
                   "name" % (n, have), file=sys.stderr)
             return 2
+        # one build (hipcc only, no GPU call) before the ranks start; they then refuse to build on their own
+        from sccav_cbf_amd import _build
+        _build.build_library()
     env = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
-               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), SCCBF_NO_REBUILD="1")
     procs = []
     for r in range(n):
         e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
@@ -338,9 +419,160 @@ def launcher(args, argv):
 
 
 # -------------------------------------------------------------------------------- a rank
+class Region:
+    """The K steps of one scaling mode on this rank: ring, batch table, and the launches of the timed region."""
+
+    def __init__(self, args, mode, rank, world, device, stub):
+        from sccav_cbf_amd.sharded import shard_bounds
+        self.mode, self.stub, self.world = mode, stub, world
+        A = args.agents
+        if mode == "strong":     # one batch per step for the whole job: this rank's contiguous block of whole tiles
+            self.lo, self.hi = shard_bounds(A, world, rank, align=64)
+            seed0 = 1234 + 4
+        else:                    # a full batch per step and rank, made from the rank's own seed
+            self.lo, self.hi = 0, A
+            seed0 = 1234 + 4 + 1000 * rank
+        self.n = self.hi - self.lo
+        self.agents_per_step = A if mode == "strong" else A * world     # of the whole job
+        self.fuse = max(1, min(args.fuse, args.ring))
+        if stub:
+            # launcher / collective plumbing rehearsal on the CPU: the "solve" is a copy, nothing is measured
+            self.ring = [dict(u_ref=torch.zeros((self.n, 2)), u_out=torch.empty((self.n, 2)),
+                              status=torch.zeros((self.n,), dtype=torch.int32)) for _ in range(args.ring)]
+            self.flt = self.table = None
+            return
+        from sccav_cbf_amd.batched import BatchTable
+        # every step reads a batch that is not touched again for RING - 1 steps: say so
+        self.flt = _filter(args.lanes, streamed=not args.no_stream_hint)
+        self.ring = make_ring(seed0, device, args.ring, agents=A, layout=args.layout, slots=args.slots,
+                              lo=self.lo, hi=self.hi)
+        self.table = BatchTable(self.ring) if self.n else None
+        self.launches = 0
+        # the launch of a whole walk over the ring, bound once (the host's share of a twenty-step region counts)
+        self.full = self.flt.bind_batches(self.table) if (self.table is not None and self.fuse == len(self.ring)) else None
+
+    def run(self, k):
+        """Steps 0 ... k - 1 of a walk over the ring, `fuse` steps per launch."""
+        ring = self.ring
+        if self.stub:
+            for i in range(k):
+                b = ring[i % len(ring)]
+                b["u_out"].copy_(b["u_ref"])
+            return
+        if self.table is None:     # a rank without agents (more ranks than tiles)
+            return
+        done, R, F = 0, len(ring), self.fuse
+        while done < k:
+            first = done % R
+            n = min(F, k - done, R - first)
+            if F == 1:
+                b = ring[first]
+                self.flt.solve(b["state"], b["u_ref"], b["obs"], b["obs_type"], u_out=b["u_out"], status=b["status"])
+            else:
+                if n == R and self.full is not None:
+                    self.full()
+                else:
+                    self.flt.solve_batches(self.table, first=first, count=n)
+            self.launches += 1
+            done += n
+
+    def launches_for(self, k):
+        R, F = len(self.ring), self.fuse
+        return (k // R) * -(-R // F) + -(-(k % R) // F)
+
+    def launch_name(self):
+        if self.stub:
+            return "cpu stub"
+        if self.fuse == 1:
+            return "one sccbf_solve_f32 launch per step, eager"
+        return ("one sccbf_solve_batches_f32 launch per %d steps: the steps are independent batches, each with its own "
+                "arrays, handed to the library as %d batch records (the bits of one sccbf_solve_f32 launch per step)"
+                % (self.fuse, self.fuse))
+
+
+def timed_region(args, reg, sync, dist, stream):
+    """Ramp, W warm-up steps, barrier, K timed steps, barrier.  Returns wall s, wall s up to the end of the closing
+    barrier, device ms (HIP events on the launch stream), ramp steps, launches in the region."""
+    def barrier():
+        sync()
+        if dist is not None:
+            dist.barrier()
+        sync()
+
+    ramp_steps = 0
+    ev0 = ev1 = None
+    if not reg.stub:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        # An idle GPU needs some ten milliseconds of work to reach its clocks, more than a short warm-up gives it.
+        # The untimed ramp runs what the timed region will run (events, launches, synchronize), several times: the
+        # first pass of anything through the runtime and the interpreter costs tens of microseconds that a region
+        # of one launch would otherwise carry.
+        k_ramp = args.steps if args.steps <= 10 * len(reg.ring) else 10 * len(reg.ring)
+        t_ramp = time.perf_counter()
+        while (time.perf_counter() - t_ramp) * 1e3 < args.ramp_ms:
+            ev0.record(stream)
+            reg.run(k_ramp)
+            ev1.record(stream)
+            sync()
+            ramp_steps += k_ramp
+    reg.run(args.warmup)
+    barrier()
+    reg.launches = 0
+    t0 = time.perf_counter()
+    if ev0 is not None:
+        ev0.record(stream)
+    reg.run(args.steps)
+    if ev1 is not None:
+        ev1.record(stream)
+    # every rank stops its own clock when its own K steps are done (the maximum over the ranks is the job's time);
+    # the closing barrier follows, and the time up to its end is reported beside it
+    sync()
+    wall = time.perf_counter() - t0
+    barrier()
+    wall_barrier = time.perf_counter() - t0
+    dev_ms = wall * 1e3 if (reg.stub or reg.table is None) else ev0.elapsed_time(ev1)
+    return wall, wall_barrier, dev_ms, ramp_steps, reg.launches
+
+
+def over_ranks(dist, device, world, wall, wall_barrier):
+    """Maximum over the ranks of both clocks, every rank's own time, and the collective library's count of the ranks."""
+    if dist is None:
+        return wall, wall_barrier, [wall], 1
+    tw = torch.tensor([wall, wall_barrier], dtype=torch.float64, device=device)
+    allw = torch.empty((2 * world,), dtype=torch.float64, device=device)
+    dist.all_gather_into_tensor(allw, tw)
+    one = torch.ones((1,), dtype=torch.int32, device=device)
+    dist.all_reduce(one, op=dist.ReduceOp.SUM)
+    allw = allw.view(world, 2).cpu()
+    return float(allw[:, 0].max()), float(allw[:, 1].max()), [float(x) for x in allw[:, 0]], int(one.item())
+
+
+def gather_cost(dist, device, world, reg, sync, reps=20):
+    """Outside the timed region: what collecting every rank's answers of one step costs (the solve itself never
+    communicates): all_gather of u_out (n, 2) f32 and status (n,) i32, blocks padded to the largest."""
+    from sccav_cbf_amd.sharded import shard_bounds
+    n = reg.n
+    if reg.mode == "strong":
+        n = max(b - a for a, b in (shard_bounds(reg.agents_per_step, world, r, 64) for r in range(world)))
+    u = torch.zeros((n, 2), dtype=torch.float32, device=device)
+    s = torch.zeros((n,), dtype=torch.int32, device=device)
+    if reg.n:
+        u[:reg.n], s[:reg.n] = reg.ring[0]["u_out"], reg.ring[0]["status"]
+    gu = torch.empty((world * n, 2), dtype=torch.float32, device=device)
+    gs = torch.empty((world * n,), dtype=torch.int32, device=device)
+    for i in range(3 + reps):
+        if i == 3:
+            sync()
+            tg = time.perf_counter()
+        dist.all_gather_into_tensor(gu, u)
+        dist.all_gather_into_tensor(gs, s)
+    sync()
+    tg = torch.tensor([(time.perf_counter() - tg) / reps * 1e3], dtype=torch.float64, device=device)
+    dist.all_reduce(tg, op=dist.ReduceOp.MAX)
+    return float(tg.item())
+
+
 def worker(args):
-    global RING
-    RING = args.ring
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -382,298 +614,213 @@ def worker(args):
 
     A, M = args.agents, ROWS
     if args.large_only:
-        # the 2^20-agent measurement on its own (what tools/prof_large.sh runs under rocprofv3)
-        from sccav_cbf_amd.batched import BatchedCBF
-        flt = BatchedCBF(alpha=1.0, lr=1.45, lf=1.45, R=np.diag([0.5, 0.5]), lanes_per_qp=args.lanes,
-                         streamed_obs=not args.no_stream_hint)
-        out = large_batch(flt, device, args.layout, args.slots, reps=args.steps if args.steps < 1000 else 200,
-                          graph=not args.no_graph)
+        # the 2^20-agent measurement on its own (what tools/prof_kernel.sh --large-only runs under rocprofv3)
+        out = large_batch(_filter(args.lanes, streamed=not args.no_stream_hint), device, args.layout, args.slots,
+                          reps=args.steps if args.steps < 1000 else 200, graph=not args.no_graph)
         out["large_only"] = True
         print(json.dumps(out), flush=True)
         return 0
-    if stub:
-        # launcher / collective plumbing rehearsal on the CPU: the "solve" is a copy, nothing is measured
-        ring = [dict(u_ref=torch.zeros((A, 2)), u_out=torch.empty((A, 2)),
-                     status=torch.zeros((A,), dtype=torch.int32)) for _ in range(RING)]
 
-        def step(i):
-            b = ring[i % RING]
-            b["u_out"].copy_(b["u_ref"])
-        sync = (lambda: None)
-        flt = None
-    else:
-        from sccav_cbf_amd.batched import BatchedCBF
-        # every step reads a batch that is not touched again for RING - 1 steps: say so
-        flt = BatchedCBF(alpha=1.0, lr=1.45, lf=1.45, R=np.diag([0.5, 0.5]), lanes_per_qp=args.lanes,
-                         streamed_obs=not args.no_stream_hint)
-        ring = make_ring(rank, device, RING, agents=A, layout=args.layout, slots=args.slots)
+    sync = (lambda: None) if stub else torch.cuda.synchronize
+    stream = None if stub else torch.cuda.Stream(device)
+    ctx = torch.cuda.stream(stream) if stream is not None else None
+    if ctx is not None:
+        ctx.__enter__()
+    try:
+        reg = Region(args, args.scaling, rank, world, device, stub)
+        wall, wall_barrier, dev_ms, ramp_steps, launches = timed_region(args, reg, sync, dist, stream)
+        wall, wall_barrier, rank_walls, coll_ranks = over_ranks(dist, device, world, wall, wall_barrier)
+        gather_ms = gather_cost(dist, device, world, reg, sync) if dist is not None else None
 
-        def step(i):
-            b = ring[i % RING]
-            flt.solve(b["state"], b["u_ref"], b["obs"], b["obs_type"], u_out=b["u_out"], status=b["status"])
-        sync = torch.cuda.synchronize
-
-    def barrier():
-        sync()
-        if dist is not None:
-            dist.barrier()
-        sync()
-
-    # one hipGraph = one walk over the ring; eager launches cover the remainder
-    graph = None
-    ramp_steps = 0
-    if stub:
-        for i in range(args.warmup):
-            step(i)
-        barrier()
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            step(i)
-        sync()
-        wall = time.perf_counter() - t0
-        barrier()
-        wall_barrier = time.perf_counter() - t0
-        dev_ms = wall * 1e3
-    else:
-        stream = torch.cuda.Stream(device)
-        with torch.cuda.stream(stream):
-            # launches per captured walk: whole walks over the ring, one replay for a short timed region.
-            # The steps are independent (every step has its own batch and its own outputs), so the captured
-            # walk deals them to `branches` parallel branches of the graph (side streams forked from and joined
-            # to the capture stream): while one launch waits for its data another one computes.
-            glen = RING * max(1, -(-min(max(args.steps, 10), 100) // RING))
-            nb = 1 if args.no_graph else max(1, args.branches)
-            for i in range(glen):
-                step(i)
-            torch.cuda.synchronize()
-
-            def capture(branches, n=None):
-                from sccav_cbf_amd.batched import capture_independent
-                return capture_independent([(lambda i=i: step(i)) for i in range(n or glen)], branches, stream)
-            if not args.no_graph:
-                graph = capture(nb)
-
-            def run(k):
-                done = 0
-                if graph is not None:
-                    for _ in range(k // glen):
-                        graph.replay()
-                    done = (k // glen) * glen
-                for i in range(done, k):
-                    step(i)
-
-            # An idle GPU needs some ten milliseconds of work to reach its clocks, more than a short
-            # warm-up gives it: untimed walks over the ring first, then the W warm-up steps.
-            t_ramp = time.perf_counter()
-            while (time.perf_counter() - t_ramp) * 1e3 < args.ramp_ms:
-                run(10 * glen)
-                torch.cuda.synchronize()
-                ramp_steps += 10 * glen
-            run(args.warmup)
-            barrier()
-            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            t0 = time.perf_counter()
-            ev0.record(stream)
-            run(args.steps)
-            ev1.record(stream)
-            # every rank stops its own clock when its own K steps are done (the maximum over the ranks is the
-            # job's time); the closing barrier follows, and the time up to its end is reported beside it
-            sync()
-            wall = time.perf_counter() - t0
-            barrier()
-            wall_barrier = time.perf_counter() - t0
-            dev_ms = ev0.elapsed_time(ev1)
-            # the same steps one at a time (a serial graph), outside the timed region: what a caller whose
-            # launches depend on each other gets, and what a per-kernel profile shows; and the proof that the
-            # overlapped walk wrote the same answers
-            serial_ms = None
-            if graph is not None and nb > 1:
-                got = [(b["u_out"].clone(), b["status"].clone()) for b in ring]
-                g1 = capture(1)
-                n1 = max(2, min(20, 2000 // glen))
-                for _ in range(n1):
-                    g1.replay()
-                torch.cuda.synchronize()
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record(stream)
-                for _ in range(n1):
-                    g1.replay()
-                e1.record(stream)
-                torch.cuda.synchronize()
-                serial_ms = e0.elapsed_time(e1) / (n1 * glen)
-                same_answers = all(torch.equal(u, b["u_out"]) and torch.equal(st, b["status"])
-                                   for (u, st), b in zip(got, ring))
-            # a timed region of a few hundred steps is mostly the start of one graph and the closing
-            # synchronize: the same measurement over 20000 steps, outside the timed region, beside it
-            steady = None
-            if graph is not None and args.steps < 5000:
-                g100 = capture(nb, 10 * RING)
-                for _ in range(50):
-                    g100.replay()
-                torch.cuda.synchronize()
-                n_st = 200
-                ts = time.perf_counter()
-                for _ in range(n_st):
-                    g100.replay()
-                torch.cuda.synchronize()
-                st_ms = (time.perf_counter() - ts) * 1e3 / (n_st * 10 * RING)
-                steady = {"steps": n_st * 10 * RING, "ms_per_step": st_ms, "value": A / (st_ms * 1e-3),
-                          "launch": "hipGraphs of %d launches in %d parallel branch(es)" % (10 * RING, nb),
-                          "note": "this rank, wall clock, outside the timed region"}
-                if nb > 1:
-                    # the other way to keep three launches in flight: one SERIAL graph per stream, three streams side
-                    # by side (no fork / join inside a graph; a third of the host time per launch)
-                    from sccav_cbf_amd.batched import capture_independent
-                    ss = [torch.cuda.Stream(device) for _ in range(3)]
-                    gs = []
-                    for j, s_ in enumerate(ss):
-                        s_.wait_stream(stream)
-                        with torch.cuda.stream(s_):
-                            gs.append(capture_independent([(lambda i=i: step(i)) for i in range(j, 30 * RING, 3)], 1, s_))
-
-                    def walk(n):
-                        for _ in range(n):
-                            for s_, g_ in zip(ss, gs):
-                                with torch.cuda.stream(s_):
-                                    g_.replay()
-                    walk(20)
-                    torch.cuda.synchronize()
-                    n_w = 70
-                    ts = time.perf_counter()
-                    walk(n_w)
-                    torch.cuda.synchronize()
-                    w_ms = (time.perf_counter() - ts) * 1e3 / (n_w * 30 * RING)
-                    steady["three_streams"] = {"steps": n_w * 30 * RING, "ms_per_step": w_ms, "value": A / (w_ms * 1e-3),
-                                               "launch": "a serial hipGraph of %d launches on each of 3 streams" % (10 * RING)}
-                    for s_ in ss:
-                        stream.wait_stream(s_)
-
-    # max over ranks of the timed region; every rank's own time; proof that the collective
-    # library saw every rank (a sum of ones over the process group)
-    rank_ms = [wall / args.steps * 1e3]
-    coll_ranks = 1
-    if dist is not None:
-        tw = torch.tensor([wall, wall_barrier], dtype=torch.float64, device=device)
-        allw = torch.empty((2 * world,), dtype=torch.float64, device=device)
-        dist.all_gather_into_tensor(allw, tw)
-        allw, allb = allw.view(world, 2)[:, 0].contiguous(), allw.view(world, 2)[:, 1]
-        wall_barrier = float(allb.max().item())
-        one = torch.ones((1,), dtype=torch.int32, device=device)
-        dist.all_reduce(one, op=dist.ReduceOp.SUM)
-        sync()
-        rank_ms = [float(x) / args.steps * 1e3 for x in allw.cpu()]
-        wall = float(allw.max().item())
-        coll_ranks = int(one.item())
-
-    # Outside the timed region: what collecting every rank's answers costs per step (the solve
-    # itself never communicates).  all_gather of u_out (A,2) f32 and status (A,) i32.
-    gather_ms = None
-    if dist is not None:
-        gu = torch.empty((world * A, 2), dtype=torch.float32, device=device)
-        gs = torch.empty((world * A,), dtype=torch.int32, device=device)
-        reps = 20
-        for i in range(3 + reps):
-            if i == 3:
-                sync()
-                tg = time.perf_counter()
-            dist.all_gather_into_tensor(gu, ring[0]["u_out"])
-            dist.all_gather_into_tensor(gs, ring[0]["status"])
-        sync()
-        tg = torch.tensor([(time.perf_counter() - tg) / reps * 1e3], dtype=torch.float64, device=device)
-        dist.all_reduce(tg, op=dist.ReduceOp.MAX)
-        gather_ms = float(tg.item())
-
-    status = torch.stack([b["status"] for b in ring]).cpu().numpy()
-    counts = np.bincount(status.reshape(-1), minlength=3)
-
-    rc = 0
-    if rank == 0:
-        total_solves = A * args.steps * world
-        value = total_solves / wall
-        kern_ms = dev_ms / args.steps           # device time per step over the timed region
-        abytes = algorithmic_bytes(A, M)
-        achieved = abytes / (kern_ms * 1e-3) / 1e9
-        layout_name = {"tiles": "tiles (A/64,M,2,64,4)", "planes": "planes (M,2,A,4)"}[args.layout]
-        out = {
-            "metric": "CBF-QP solves/sec (2-input, 16-constraint)",
-            "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": "C4: %d agents x 16 obstacle rows (8 ellipse + 8 collision cone) per GPU, "
-                                   "DBM filter, alpha=1, R=diag(.5,.5), ring of %d distinct batches" % (A, RING),
-                       "agents_per_gpu": A, "rows": M, "lanes_per_qp": args.lanes,
-                       "obs_layout": layout_name,
-                       "obs_slots": "prepared (kinds 4, 5: 1/a^2, 1/b^2, cos, sin and the cone's obstacle velocity "
-                                    "stored in the slot)" if args.slots == "prepared" else "as written (kinds 0, 1)",
-                       "launch": "eager" if graph is None else ("hipGraph of %d launches" % glen if nb == 1 else
-                                                                "hipGraph of %d launches in %d parallel branches (the steps "
-                                                                "are independent batches: their launches overlap)" % (glen, nb)),
-                       "clock_ramp_steps_before_warmup": ramp_steps},
-            # achieved = algorithmic bytes of the timed region's launches / its device time (HIP events); with
-            # overlapping launches kernel_ms is the time per launch of the walk, not one kernel's own duration
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": _profile_json("traffic.json"),
-                         "kernel_ms": kern_ms,
-                         "algorithmic_bytes_per_launch": abytes},
-            "status_counts": {"optimal": int(counts[0]), "infeasible": int(counts[1]),
-                              "nonfinite": int(counts[2])},
-            # QPs whose rows admit no input: the filter reports status 1 and hands back the nominal input
-            "infeasible_fraction": float(counts[1]) / max(1, int(counts.sum())),
-        }
-        if not stub and serial_ms is not None:
-            out["roofline"]["concurrent_launches"] = nb
-            out["roofline"]["note"] = ("independent steps overlap (%d launches in flight): achieved = bytes of the timed "
-                                       "region's launches / its device time; kernel_ms is that time per launch, not one "
-                                       "kernel's own duration, which one_at_a_time gives (rocprofv3 --kernel-trace "
-                                       "serialises concurrent kernels and shows that one)" % nb)
-            out["roofline"]["one_at_a_time"] = {
-                "kernel_ms": serial_ms, "achieved": abytes / (serial_ms * 1e-3) / 1e9,
-                "frac": abytes / (serial_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                "note": "the same launches from a serial graph: one kernel's own duration, what rocprofv3 "
-                        "--kernel-trace shows per kernel and what a chain of dependent launches gets"}
-            out["roofline"]["overlapped_answers_equal_serial"] = bool(same_answers)
-        if not stub and steady is not None:
-            steady["roofline_frac"] = abytes / (steady["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBPS
-            if "three_streams" in steady:
-                steady["three_streams"]["roofline_frac"] = (abytes / (steady["three_streams"]["ms_per_step"] * 1e-3) / 1e9
-                                                            / HBM_PEAK_GBPS)
-            out["steady_state"] = steady
-        if stub:
-            out["data"] = "none (cpu stub: launcher rehearsal, nothing measured)"
-            out["stub"] = True
-            out["roofline"] = None
-        if dist is not None:
-            out["rccl_ranks" if not stub else "gloo_ranks"] = coll_ranks
-            out["ms_per_step_by_rank"] = rank_ms
-            # the clock of ms_per_step stops when the rank's own steps are done; this one after the closing barrier
-            out["ms_per_step_to_end_of_closing_barrier"] = wall_barrier / args.steps * 1e3
-            out["gather_ms_per_step"] = gather_ms   # not part of value / ms_per_step
+        # the other scaling mode beside it (N > 1): the same region on the other partition of the work
+        other = None
+        if world > 1 and not args.no_other_scaling:
+            omode = "strong" if args.scaling == "weak" else "weak"
+            del reg.ring, reg.table
+            oreg = Region(args, omode, rank, world, device, stub)
+            ow, owb, odev, _, ol = timed_region(args, oreg, sync, dist, stream)
+            ow, owb, owalls, _ = over_ranks(dist, device, world, ow, owb)
+            og = gather_cost(dist, device, world, oreg, sync) if dist is not None else None
+            other = {"scaling": omode, "value": oreg.agents_per_step * args.steps / ow, "unit": "solves/s",
+                     "ms_per_step": ow / args.steps * 1e3, "agents_per_rank_and_step": oreg.n,
+                     "agents_per_step_whole_job": oreg.agents_per_step,
+                     "ms_per_step_by_rank": [x / args.steps * 1e3 for x in owalls],
+                     "ms_per_step_with_all_gather": ow / args.steps * 1e3 + (og or 0.0),
+                     "gather_ms_per_step": og, "launches": ol}
+        rc = 0
+        if rank == 0:
+            out = headline(args, world, wall, wall_barrier, dev_ms, ramp_steps, launches, rank_walls, coll_ranks,
+                           gather_ms, dist, stub, A, M,
+                           reg_info=(reg.mode, reg.n, reg.agents_per_step, reg.fuse, reg.launch_name()))
+            if other is not None:
+                out["other_scaling"] = other
             if coll_ranks != world:
                 print("bench.py: the collective saw %d ranks, expected %d" % (coll_ranks, world), file=sys.stderr)
                 rc = 1
-        if world == 1 and not stub and not args.no_large and A == AGENTS:
-            try:
-                del ring
-                torch.cuda.empty_cache()
-                out["roofline_large_batch"] = large_batch(flt, device, args.layout, args.slots)
-            except Exception as e:  # extra information only
-                out["roofline_large_batch"] = {"error": repr(e)}
-        if world == 1 and not stub and not args.no_fp64 and A == AGENTS:
-            try:
-                out["fp64"] = fp64_lines(device)
-            except Exception as e:
-                out["fp64"] = {"error": repr(e)}
-        if world == 1 and not stub and not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
-        if _saved_stdout is not None:
-            sys.stdout.flush()
-            os.dup2(_saved_stdout, 1)
-        print(json.dumps(out), flush=True)
+            if world == 1 and not stub and not args.headline_only:
+                extras(args, out, reg, device, stream)
+            if _saved_stdout is not None:
+                sys.stdout.flush()
+                os.dup2(_saved_stdout, 1)
+            print(json.dumps(out), flush=True)
+    finally:
+        if ctx is not None:
+            ctx.__exit__(None, None, None)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     return rc
+
+
+def headline(args, world, wall, wall_barrier, dev_ms, ramp_steps, launches, rank_walls, coll_ranks, gather_ms,
+             dist, stub, A, M, reg_info):
+    mode, n_rank, per_step, fuse, launch_name = reg_info
+    value = per_step * args.steps / wall
+    ms_step = wall / args.steps * 1e3
+    ab_step = algorithmic_bytes(n_rank, M)                 # this rank's bytes per step
+    kern_ms_step = dev_ms / args.steps
+    launches = max(1, launches)
+    layout_name = {"tiles": "tiles (A/64,M,2,64,4)", "planes": "planes (M,2,A,4)"}[args.layout]
+    if mode == "strong":
+        workload = ("C4 as stated: ONE batch of %d agents x 16 obstacle rows (8 ellipse + 8 collision cone) per step, "
+                    "contiguous blocks of %d agents per GPU, DBM filter, alpha=1, R=diag(.5,.5), ring of %d distinct "
+                    "batches" % (A, n_rank, args.ring))
+    else:
+        workload = ("C4: %d agents x 16 obstacle rows (8 ellipse + 8 collision cone) per GPU and step, DBM filter, alpha=1, "
+                    "R=diag(.5,.5), ring of %d distinct batches" % (A, args.ring))
+    out = {
+        "metric": "CBF-QP solves/sec (2-input, 16-constraint)",
+        "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": ms_step,
+        "higher_is_better": True, "scaling": mode, "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": workload, "agents_per_gpu": n_rank, "agents_per_step_whole_job": per_step, "rows": M,
+                   "lanes_per_qp": args.lanes, "obs_layout": layout_name,
+                   "obs_slots": "prepared (kinds 4, 5: 1/a^2, 1/b^2, cos, sin and the cone's obstacle velocity are stored in "
+                                "the slot, evaluated before the timed region)" if args.slots == "prepared"
+                                else "as written (kinds 0, 1)",
+                   "launch": launch_name, "batches_per_launch": fuse, "launches_in_timed_region": launches,
+                   "clock_ramp_steps_before_warmup": ramp_steps},
+    }
+    if not stub:
+        # achieved = algorithmic bytes of the timed region's launches / its device time (HIP events on the launch stream)
+        achieved = ab_step / (kern_ms_step * 1e-3) / 1e9
+        out["roofline"] = {
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+            "traffic": _profile_json("traffic.json") if (fuse == RING and n_rank == AGENTS) else None,
+            "kernel_ms": dev_ms / launches, "algorithmic_bytes_per_launch": ab_step * args.steps // launches,
+            "batches_per_launch": args.steps / launches, "kernel_ms_per_step": kern_ms_step,
+            "algorithmic_bytes_per_step": ab_step,
+            "frac_by_wall_clock": frac_of_peak(ab_step, rank_walls[0] / args.steps * 1e3),
+            "note": "achieved = algorithmic bytes of the timed region's launches / its device time by two HIP events on "
+                    "the launch stream around the region; frac_by_wall_clock = the same bytes over this rank's host clock (ms_per_step at N = 1); "
+                    "traffic = HBM bytes per launch by the FETCH_SIZE / WRITE_SIZE counters of a profiler run of this "
+                    "command on these sources (profiles/), null when there is none"}
+    else:
+        out["data"] = "none (cpu stub: launcher rehearsal, nothing measured)"
+        out["stub"] = True
+        out["roofline"] = None
+    if dist is not None:
+        out["rccl_ranks" if not stub else "gloo_ranks"] = coll_ranks
+        out["ms_per_step_by_rank"] = [x / args.steps * 1e3 for x in rank_walls]
+        # the clock of ms_per_step stops when the rank's own steps are done; this one after the closing barrier
+        out["ms_per_step_to_end_of_closing_barrier"] = wall_barrier / args.steps * 1e3
+        out["gather_ms_per_step"] = gather_ms   # not part of value / ms_per_step
+        out["ms_per_step_with_all_gather"] = ms_step + (gather_ms or 0.0)
+    return out
+
+
+def extras(args, out, reg, device, stream):
+    """N = 1: what stands beside the headline.  Nothing here enters value / ms_per_step."""
+    A, M = args.agents, ROWS
+    flt, ring = reg.flt, reg.ring
+    ab = algorithmic_bytes(A, M)
+    status = torch.stack([b["status"] for b in ring]).cpu().numpy()
+    counts = np.bincount(status.reshape(-1), minlength=3)
+    out["status_counts"] = {"optimal": int(counts[0]), "infeasible": int(counts[1]), "nonfinite": int(counts[2])}
+    # QPs whose rows admit no input: the filter reports status 1 and hands back the nominal input
+    out["infeasible_fraction"] = float(counts[1]) / max(1, int(counts.sum()))
+    r = out["roofline"]
+    try:
+        # the same steps one launch at a time (a serial hipGraph of sccbf_solve_f32 launches): what a caller whose
+        # launches depend on each other gets; and the proof that the fused launch wrote the same answers
+        got = [(b["u_out"].clone(), b["status"].clone()) for b in ring]
+        steps = [_solve_fn(flt, b) for b in ring]
+        serial_ms = _time_graph(steps, stream, 20)
+        same = all(torch.equal(u, b["u_out"]) and torch.equal(st, b["status"]) for (u, st), b in zip(got, ring))
+        r["one_at_a_time"] = {"kernel_ms": serial_ms, "achieved": ab / (serial_ms * 1e-3) / 1e9,
+                              "frac": frac_of_peak(ab, serial_ms),
+                              "note": "one sccbf_solve_f32 launch per step from a serial hipGraph: one kernel's own "
+                                      "duration, what a chain of dependent launches gets"}
+        r["fused_answers_equal_separate_launches"] = bool(same)
+        # the same launches overlapping on three parallel branches of a hipGraph
+        br_ms = _time_graph(steps * 5, stream, 20, branches=args.branches)
+        r["branched_graph"] = {"ms_per_step": br_ms, "frac": frac_of_peak(ab, br_ms), "branches": args.branches,
+                               "note": "one sccbf_solve_f32 launch per step, the launches of independent steps overlapping on "
+                                       "parallel branches of one hipGraph"}
+    except Exception as e:
+        r["one_at_a_time"] = {"error": repr(e)}
+    if args.steps < 5000:
+        # a timed region of twenty steps is ONE launch between two synchronisations: the same measurement over
+        # 4000 steps, outside the timed region, beside it
+        try:
+            n_st = 200
+            ms = _events_ms(lambda: flt.solve_batches(reg.table), stream, n_st) / len(ring)
+            ts = time.perf_counter()
+            for _ in range(n_st):
+                flt.solve_batches(reg.table)
+            torch.cuda.synchronize()
+            st_ms = (time.perf_counter() - ts) * 1e3 / (n_st * len(ring))
+            out["steady_state"] = {"steps": n_st * len(ring), "ms_per_step": st_ms, "value": A / (st_ms * 1e-3),
+                                   "ms_per_step_by_events": ms, "launch": reg.launch_name(),
+                                   "roofline_frac": frac_of_peak(ab, st_ms),
+                                   "note": "wall clock over 200 launches, outside the timed region"}
+        except Exception as e:
+            out["steady_state"] = {"error": repr(e)}
+    if args.quick or A != AGENTS or args.layout != "tiles":
+        if not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, args.slots)
+        return
+    c4 = {"us_per_step": r["kernel_ms_per_step"] * 1e3, "solves_per_s": A / (r["kernel_ms_per_step"] * 1e-3),
+          "frac": r["frac"], "dtype": "f32", "launch": "twenty batches per launch (the headline's timed region)"}
+    if "one_at_a_time" in r and "frac" in r["one_at_a_time"]:
+        c4["one_launch_per_step"] = {"us_per_step": r["one_at_a_time"]["kernel_ms"] * 1e3, "frac": r["one_at_a_time"]["frac"]}
+    for key, fn in (
+            # slots as the reference's objects hold them (kinds 0, 1): sin / cos / reciprocals per slot inside the launch
+            ("slots_as_written", lambda: written_section(args, device, stream)),
+            ("variants", lambda: variants_section(ring, device, stream)),
+            ("c4_shard", lambda: shard_section(flt, ring, stream))):
+        try:
+            out[key] = fn()
+        except Exception as e:  # extra information only
+            out[key] = {"error": repr(e)}
+    if isinstance(out.get("slots_as_written"), dict) and "one_launch_per_step" in out["slots_as_written"]:
+        # what a closed loop gets: one dependent launch per tick, slots as written
+        out["value_serial_written"] = out["slots_as_written"]["one_launch_per_step"]["solves_per_s"]
+    del reg.ring, reg.table, ring
+    torch.cuda.empty_cache()
+    try:
+        out["configs"] = configs_section(device, c4)
+        cf = out["configs"]
+        out["fp64"] = {"c4": cf["c4"]["f64"], "c5": cf["c5"]["f64"], "c2": cf["c2"]}
+    except Exception as e:
+        out["configs"] = {"error": repr(e)}
+    if not args.no_large:
+        try:
+            torch.cuda.empty_cache()
+            out["roofline_large_batch"] = large_batch(flt, device, args.layout, args.slots)
+        except Exception as e:
+            out["roofline_large_batch"] = {"error": repr(e)}
+    if not args.no_cpu:
+        out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, args.slots)
+
+
+def written_section(args, device, stream):
+    flt = _filter(args.lanes, streamed=not args.no_stream_hint)
+    ring = make_ring(1234 + 4, device, RING, slots="written")
+    fused, single = fused_and_single(flt, ring, stream)
+    return {"obs_slots": "as written (kinds 0, 1)", "twenty_batches_per_launch": _line(AGENTS, ROWS, fused),
+            "one_launch_per_step": _line(AGENTS, ROWS, single)}
 
 
 def main():
@@ -681,9 +828,17 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20000)
     ap.add_argument("--warmup", type=int, default=5000)
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: a full 65536-agent batch per GPU and step; strong: one 65536-agent batch per step, "
+                         "contiguous blocks of 65536 / N agents per GPU.  With N > 1 the line carries the other mode too "
+                         "(other_scaling)")
+    ap.add_argument("--no-other-scaling", action="store_true", help="N > 1: only the mode --scaling names")
+    ap.add_argument("--fuse", type=int, default=RING,
+                    help="steps per launch (sccbf_solve_batches_f32 over that many batch records); 1 = one sccbf_solve_f32 "
+                         "launch per step")
     ap.add_argument("--lanes", type=int, default=0, help="lanes per QP (0 = library default)")
     ap.add_argument("--agents", type=int, default=AGENTS)
-    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--no-graph", action="store_true", help="--large-only: launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
     ap.add_argument("--cpu-seconds", type=float, default=10.0,
                     help="length of the all-threads sample of the CPU baseline (the one-thread sample takes 0.4 of it)")
@@ -694,15 +849,17 @@ def main():
     ap.add_argument("--no-stream-hint", action="store_true",
                     help="do not tell the library that each step's obstacle slots are read once (SCCBF_FLAG_OBS_STREAMED)")
     ap.add_argument("--branches", type=int, default=3,
-                    help="parallel branches of the captured walk (independent steps overlap); 1 = one launch at a time")
+                    help="parallel branches of the hipGraph in roofline.branched_graph")
     ap.add_argument("--ring", type=int, default=RING,
-                    help="distinct batches the steps walk over (default 10: more than the Infinity Cache holds, every "
-                         "step streams from HBM; 1: the same batch every step, served from the Infinity Cache, which "
-                         "shows what the arithmetic alone costs)")
+                    help="distinct batches the steps walk over (default 20: 718 MB, every step streams from HBM)")
+    ap.add_argument("--quick", action="store_true",
+                    help="N = 1: only the headline, its one-at-a-time / branched figures and the CPU baseline")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="N = 1: nothing beside the headline (what the profiler scripts run: every kernel in the trace is "
+                         "the timed region's)")
     ap.add_argument("--no-large", action="store_true", help="skip the extra 1M-agent measurement (N=1 only)")
     ap.add_argument("--large-only", action="store_true",
                     help="only the 2^20-agent measurement (with --steps < 1000: that many walks over its ring of 3)")
-    ap.add_argument("--no-fp64", action="store_true", help="skip the fp64 lines (N=1 only)")
     ap.add_argument("--ramp-ms", type=float, default=60.0,
                     help="untimed work ahead of the warm-up steps that lets an idle GPU reach its clocks")
     ap.add_argument("--cpu-stub", action="store_true",

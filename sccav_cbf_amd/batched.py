@@ -154,6 +154,27 @@ class BatchedCBF:
             return u_out, status, rows_out
         return u_out, status
 
+    def bind_batches(self, table, first=0, count=None):
+        """solve_batches(table, first, count) with everything looked up and converted once: returns launch(),
+        which enqueues the launch on `stream` (default: the stream current NOW) and costs the host a few
+        microseconds less per call.  The filter's parameters are read at bind time."""
+        K = len(table) - first if count is None else int(count)
+        if first < 0 or K < 0 or first + K > len(table):
+            raise ValueError("batches %d ... %d of a table of %d" % (first, first + K, len(table)))
+        params = _lib.Params.from_buffer_copy(self.params)
+        params.flags = (table.flags | (FLAG_SLIP_IO if self.slip_io else 0)
+                        | (_lib.FLAG_OBS_STREAMED if self.streamed_obs else 0))
+        fn = self._lib.sccbf_solve_batches_f32 if table.dtype == torch.float32 else self._lib.sccbf_solve_batches_f64
+        args = (C.byref(params), C.c_int32(K), C.c_int32(table.M), C.c_int64(table.a_max(first, K)),
+                C.c_void_p(table.records.data_ptr() + 64 * first),
+                C.c_void_p(torch.cuda.current_stream(table.device).cuda_stream))
+        check = _lib.check
+
+        def launch():
+            check(fn(*args))
+        launch._keep = (params, table)
+        return launch
+
     def solve_batches(self, table, first=0, count=None):
         """One launch for `count` batches of a BatchTable from record `first` on (default: all of them):
         sccbf_solve_batches_*, the answers of solve() called per batch, bit for bit, at the memory rate of

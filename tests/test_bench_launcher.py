@@ -24,6 +24,26 @@ def test_gpus_2_starts_two_ranks_and_the_collective_sees_both():
     assert out["n_gpus"] == 2 and out["gloo_ranks"] == 2 and out["stub"] is True
     assert len(out["ms_per_step_by_rank"]) == 2 and out["gather_ms_per_step"] >= 0.0
     assert out["steps"] == 20 and out["scaling"] == "weak"
+    assert out["config"]["agents_per_gpu"] == 256 and out["config"]["agents_per_step_whole_job"] == 512
+    # the other partition of the work beside it: one 256-agent batch per step, 128 agents per rank
+    o = out["other_scaling"]
+    assert o["scaling"] == "strong" and o["agents_per_rank_and_step"] == 128 and o["agents_per_step_whole_job"] == 256
+    assert len(o["ms_per_step_by_rank"]) == 2 and o["gather_ms_per_step"] >= 0.0
+
+
+def test_strong_scaling_line_shards_one_batch_over_the_ranks():
+    r = _run(["--gpus", "2", "--cpu-stub", "--steps", "20", "--warmup", "5", "--agents", "320", "--scaling", "strong"])
+    assert r.returncode == 0, r.stderr
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][-1])
+    assert out["n_gpus"] == 2 and out["gloo_ranks"] == 2 and out["scaling"] == "strong"
+    # 320 agents = 5 tiles of 64: blocks of whole tiles, rank 0 holds three of them
+    assert out["config"]["agents_per_gpu"] == 192 and out["config"]["agents_per_step_whole_job"] == 320
+    assert "contiguous blocks" in out["config"]["workload"]
+    assert abs(out["value"] - 320 * 20 / (out["ms_per_step"] * 20 * 1e-3)) <= 1e-6 * out["value"]
+    assert out["other_scaling"]["scaling"] == "weak" and out["other_scaling"]["agents_per_step_whole_job"] == 640
+    r = _run(["--gpus", "2", "--cpu-stub", "--steps", "4", "--warmup", "1", "--agents", "256", "--scaling", "strong",
+              "--no-other-scaling"])
+    assert r.returncode == 0 and "other_scaling" not in json.loads(r.stdout.strip().splitlines()[-1])
 
 
 def test_gpus_beyond_the_visible_devices_is_an_error_not_a_smaller_job():
