@@ -145,13 +145,25 @@ typedef struct sccbf_params {
                              tables fit (64 / lanes tables of 3 M values per wavefront, 64 KB):
                              64 = one wavefront per QP.  Tables beyond 64 KB per workgroup need a
                              function attribute that the first such launch on a device sets
-                             (hipFuncSetAttribute): make that launch outside stream capture */
+                             (hipFuncSetAttribute): make that launch outside stream capture, or
+                             call sccbf_prewarm() first */
     uint32_t flags;       /* SCCBF_FLAG_* */
     int32_t reserved;
 } sccbf_params;
 
 int sccbf_version(void);
 const char* sccbf_strerror(int code);
+
+/*
+ * Optional set-up of the current device, everything the library otherwise does on first use: the function attribute
+ * that lets the kernels for long row lists (rows in LDS only, M > 128 or lanes_per_qp 32 / 64) take more than 64 KB
+ * of LDS, for every such kernel, and the address of the table of sccbf_solve_batches_static.  Neither may happen
+ * under stream capture: a caller that captures its first launch of a kind calls this once per device beforehand
+ * (with that device current).  SCCBF_OK, or SCCBF_ERR_NO_DEVICE when the runtime refuses.  No counterpart in the
+ * reference.  The library reads and clears no runtime error state: every entry point reports its own launch's
+ * result (hipLaunchKernel's return value) and leaves hipGetLastError() to the caller.
+ */
+int sccbf_prewarm(void);
 
 /* Writes the defaults of the reference objects: alpha 1 (cbf.py:128), R = I
  * (cbf.py:134), zero_tol 1e-3, lr = lf = 1.45, L = 2.9

@@ -31,7 +31,7 @@ EXPORTS = ("sccbf_version", "sccbf_strerror", "sccbf_default_params", "sccbf_sol
            "sccbf_lane_fit_f32", "sccbf_lane_fit_f64", "sccbf_solve_step_f32", "sccbf_solve_step_f64",
            "sccbf_prepare_obs_f32", "sccbf_prepare_obs_f64", "sccbf_vehicle_step_kin_f32",
            "sccbf_vehicle_step_kin_f64", "sccbf_solve_batches_f32", "sccbf_solve_batches_f64",
-           "sccbf_solve_batches_static")
+           "sccbf_solve_batches_static", "sccbf_prewarm")
 MOTION_STATIC, MOTION_CONSTANT_VELOCITY, MOTION_SEEKER = 0, 1, 2
 STEP_KIN_ACC, STEP_KIN_VEL, STEP_UNICYCLE = 0, 1, 2
 NOMINAL_WAYPOINT_SPEED = 1
@@ -168,10 +168,12 @@ def _bind(L):
         f.restype = C.c_int
         f.argtypes = [C.c_int64, vp, vp, C.c_int32, C.c_double, C.c_double, C.c_double, vp]
     for name in ("sccbf_solve_batches_f32", "sccbf_solve_batches_f64",
-           "sccbf_solve_batches_static"):
+           "sccbf_solve_batches_static", "sccbf_prewarm"):
         f = getattr(L, name)
         f.restype = C.c_int
         f.argtypes = [C.POINTER(Params), C.c_int32, C.c_int32, C.c_int64, vp, vp]
+    L.sccbf_prewarm.restype = C.c_int
+    L.sccbf_prewarm.argtypes = []
     L.sccbf_solve_batches_static.restype = C.c_int
     L.sccbf_solve_batches_static.argtypes = [C.POINTER(Params), C.c_int32, C.c_int32, C.c_int32, vp, vp]
     _lib = L

@@ -208,8 +208,17 @@ class BatchedCBF:
                                                       K, table.M, C.c_void_p(rec.ctypes.data), C.c_void_p(stream))
         _lib.check(rc)
 
-    def prepare_obs(self, obs, obs_type, agents=None):
-        """As-written ellipse / cone slots -> their prepared kinds, in place: the module's prepare_obs()."""
+    def prepare_obs(self, obs, obs_type, agents=None, frozen_cone_beta=False):
+        """As-written ellipse / cone slots -> their prepared kinds, in place: the module's prepare_obs().
+        A prepared cone keeps the beta it was prepared with.  The steer-rate model hands every cone the agent's
+        slip angle after each solve (reference cbf/cbf.py:424-427; cone_beta_state=True here), which a prepared
+        cone cannot follow: with dynamics "sadbm" and collision cones among the slots this raises unless
+        frozen_cone_beta=True says that the frozen value is wanted."""
+        if (self.params.dynamics == _lib.DYN_SADBM and not frozen_cone_beta
+                and bool((obs_type == OBS_CONE).any().item())):
+            raise ValueError("prepare_obs with dynamics 'sadbm': prepared collision cones keep the beta they were prepared "
+                             "with and do not follow the agent's slip angle (cone_beta_state); keep the cones as written, "
+                             "or pass frozen_cone_beta=True")
         return prepare_obs(obs, obs_type, agents)
 
     def solve_qp(self, rows, u_nom, u_out=None, status=None):
@@ -287,6 +296,13 @@ class BatchTable:
     def a_max(self, first=0, count=None):
         part = self.agents[first:] if count is None else self.agents[first:first + count]
         return max(part) if part else 0
+
+
+def prewarm():
+    """Device set-up that the library otherwise does on first use and that may not happen under stream capture
+    (sccbf_prewarm): call it once, with the device current, before capturing a first launch with more than 128
+    rows per QP or the first solve_batches_static."""
+    _lib.check(_lib.load().sccbf_prewarm())
 
 
 def prepare_obs(obs, obs_type, agents=None):

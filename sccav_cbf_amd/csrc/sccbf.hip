@@ -28,6 +28,8 @@
 // models), sccbf_ingest.hip.h (bounding boxes and lane points -> slots); this file: host-side
 // dispatch and the C ABI.
 #include <atomic>
+#include <tuple>
+#include <utility>
 
 #include "sccbf_loop.hip.h"
 #include "sccbf_ext.hip.h"
@@ -70,10 +72,30 @@
 namespace {
 
 // ------------------------------------------------------------------- host side
-// hipGetLastError() reports the last error of ANY earlier runtime call of the calling thread (another library's
-// failed probe, say) until somebody reads it.  Every entry point reads it away first, so that what it reads after
-// its launch is its own launch's.
-inline void forget_earlier_errors_() { (void)hipGetLastError(); }
+// Every kernel is launched through hipLaunchKernel, whose return value is this launch's own verdict.  The runtime's
+// "last error" is never read: it may hold an error that another library left unread on this thread, which is that
+// library's to report, not this one's to consume.
+thread_local int t_launch_rc = SCCBF_OK;
+
+template <typename... P, typename... Args, size_t... I>
+void launch_impl_(void (*kernel)(P...), dim3 grid, dim3 block, size_t lds, hipStream_t s, std::index_sequence<I...>,
+                  Args&&... args)
+{
+    std::tuple<std::remove_cv_t<P>...> vals(static_cast<std::remove_cv_t<P>>(args)...);
+    void* ptrs[sizeof...(P)] = {static_cast<void*>(&std::get<I>(vals))...};
+    t_launch_rc = hipLaunchKernel(reinterpret_cast<const void*>(kernel), grid, block, ptrs, lds, s) == hipSuccess
+                      ? SCCBF_OK : SCCBF_ERR_LAUNCH;
+}
+
+template <typename... P, typename... Args>
+void launch_(void (*kernel)(P...), dim3 grid, dim3 block, size_t lds, hipStream_t s, Args&&... args)
+{
+    static_assert(sizeof...(P) == sizeof...(Args), "one argument per kernel parameter");
+    launch_impl_(kernel, grid, block, lds, s, std::index_sequence_for<P...>(), std::forward<Args>(args)...);
+}
+
+// SCCBF_OK or SCCBF_ERR_LAUNCH of the calling thread's latest launch_()
+inline int launched_() { return t_launch_rc; }
 
 template <typename T>
 int fill_args(const sccbf_params* sp, int64_t A, int32_t M, KArgs<T>& k)
@@ -138,12 +160,12 @@ int launch_group(const KArgs<T>& k, hipStream_t s)
     // rows of the QP-only entry are a third of the bytes of obstacle slots: always cached loads
     const bool nt = !QP_ONLY && ((k.flags & SCCBF_FLAG_OBS_STREAMED) || (double)k.A * k.M * 8 * sizeof(T) >= kNtBytes);
     if (nt)
-        hipLaunchKernelGGL((k_group<T, G, RPL, QP_ONLY, !QP_ONLY>), dim3((unsigned)blocks), dim3(kBlock), 0, s, k.A,
+        launch_((k_group<T, G, RPL, QP_ONLY, !QP_ONLY>), dim3((unsigned)blocks), dim3(kBlock), 0, s, k.A,
                            k.obs, k.state, k.u_ref, k.obs_type, k.M, k.flags, k);
     else
-        hipLaunchKernelGGL((k_group<T, G, RPL, QP_ONLY, false>), dim3((unsigned)blocks), dim3(kBlock), 0, s, k.A,
+        launch_((k_group<T, G, RPL, QP_ONLY, false>), dim3((unsigned)blocks), dim3(kBlock), 0, s, k.A,
                            k.obs, k.state, k.u_ref, k.obs_type, k.M, k.flags, k);
-    return hipGetLastError() == hipSuccess ? SCCBF_OK : SCCBF_ERR_LAUNCH;
+    return launched_();
 }
 
 template <typename T, bool QP_ONLY, int G>
@@ -218,8 +240,8 @@ int launch_wave_shape(const KArgs<T>& k, hipStream_t s)
     const long long blocks = wave_blocks<QPB, PAIRED>(k.A);
     if (blocks > 0x7fffffffLL) return SCCBF_ERR_ARG;
     if (!grant_lds<k_wave<T, QPB, QP_ONLY, G, PAIRED>>(lds)) return SCCBF_ERR_VARIANT;
-    hipLaunchKernelGGL((k_wave<T, QPB, QP_ONLY, G, PAIRED>), dim3((unsigned)blocks), dim3(QPB * G), lds, s, k);
-    return hipGetLastError() == hipSuccess ? SCCBF_OK : SCCBF_ERR_LAUNCH;
+    launch_((k_wave<T, QPB, QP_ONLY, G, PAIRED>), dim3((unsigned)blocks), dim3(QPB * G), lds, s, k);
+    return launched_();
 }
 
 template <typename T, bool QP_ONLY, int G>
@@ -238,8 +260,8 @@ int dispatch(const sccbf_params* sp, KArgs<T>& k, void* stream)
     if (k.M == 0) {
         const long long blocks = (k.A + kBlock - 1) / kBlock;
         if (blocks > 0x7fffffffLL) return SCCBF_ERR_ARG;
-        hipLaunchKernelGGL((k_passthrough<T, QP_ONLY>), dim3((unsigned)blocks), dim3(kBlock), 0, s, k);
-        return hipGetLastError() == hipSuccess ? SCCBF_OK : SCCBF_ERR_LAUNCH;
+        launch_((k_passthrough<T, QP_ONLY>), dim3((unsigned)blocks), dim3(kBlock), 0, s, k);
+        return launched_();
     }
     int lanes = sp->lanes_per_qp;
     if (lanes == 0) lanes = auto_lanes(k.A, k.M);
@@ -265,13 +287,13 @@ int launch_ext_rpl(const KArgs<T>& k, const XArgs<T>& x, hipStream_t s)
     if (blocks > 0x7fffffffLL) return SCCBF_ERR_ARG;
     const int rpl = (k.M + G - 1) / G;
     const dim3 grid((unsigned)blocks), block(kBlock);
-    if (rpl <= 1) hipLaunchKernelGGL((k_group_ext<T, G, 1>), grid, block, 0, s, k, x);
-    else if (rpl <= 2) hipLaunchKernelGGL((k_group_ext<T, G, 2>), grid, block, 0, s, k, x);
-    else if (rpl <= 4) hipLaunchKernelGGL((k_group_ext<T, G, 4>), grid, block, 0, s, k, x);
-    else if (rpl <= 8) hipLaunchKernelGGL((k_group_ext<T, G, 8>), grid, block, 0, s, k, x);
-    else if (rpl <= 16) hipLaunchKernelGGL((k_group_ext<T, G, 16>), grid, block, 0, s, k, x);
+    if (rpl <= 1) launch_((k_group_ext<T, G, 1>), grid, block, 0, s, k, x);
+    else if (rpl <= 2) launch_((k_group_ext<T, G, 2>), grid, block, 0, s, k, x);
+    else if (rpl <= 4) launch_((k_group_ext<T, G, 4>), grid, block, 0, s, k, x);
+    else if (rpl <= 8) launch_((k_group_ext<T, G, 8>), grid, block, 0, s, k, x);
+    else if (rpl <= 16) launch_((k_group_ext<T, G, 16>), grid, block, 0, s, k, x);
     else return SCCBF_ERR_ROWS;
-    return hipGetLastError() == hipSuccess ? SCCBF_OK : SCCBF_ERR_LAUNCH;
+    return launched_();
 }
 
 template <typename T, int G, int QPB, bool PAIRED>
@@ -281,8 +303,8 @@ int launch_wave_ext_shape(const KArgs<T>& k, const XArgs<T>& x, hipStream_t s)
     const long long blocks = wave_blocks<QPB, PAIRED>(k.A);
     if (blocks > 0x7fffffffLL) return SCCBF_ERR_ARG;
     if (!grant_lds<k_wave_ext<T, QPB, G, PAIRED>>(lds)) return SCCBF_ERR_VARIANT;
-    hipLaunchKernelGGL((k_wave_ext<T, QPB, G, PAIRED>), dim3((unsigned)blocks), dim3(QPB * G), lds, s, k, x);
-    return hipGetLastError() == hipSuccess ? SCCBF_OK : SCCBF_ERR_LAUNCH;
+    launch_((k_wave_ext<T, QPB, G, PAIRED>), dim3((unsigned)blocks), dim3(QPB * G), lds, s, k, x);
+    return launched_();
 }
 
 template <typename T, int G>
@@ -311,12 +333,30 @@ int dispatch_ext(const sccbf_params* sp, const KArgs<T>& k, const XArgs<T>& x, v
     return SCCBF_ERR_VARIANT;
 }
 
+// sccbf_prewarm: the attribute that lets a workgroup take more than 64 KB of LDS, for every kernel of this part of the
+// library that may ask for it (the kernels that keep the rows in LDS only), on the current device
+template <typename T, int G> bool prewarm_wave_()
+{
+    constexpr int kQpb = WaveShape<T, G>::kQpb;
+    bool ok = grant_lds<k_wave<T, kQpb, false, G, false>>(kLdsPerCu) & grant_lds<k_wave<T, kQpb, true, G, false>>(kLdsPerCu) &
+              grant_lds<k_wave_ext<T, kQpb, G, false>>(kLdsPerCu);
+    if (G == 64)
+        ok &= grant_lds<k_wave<T, (G == 64 ? kQpb / 2 : kQpb), false, G, G == 64>>(kLdsPerCu) &
+              grant_lds<k_wave<T, (G == 64 ? kQpb / 2 : kQpb), true, G, G == 64>>(kLdsPerCu) &
+              grant_lds<k_wave_ext<T, (G == 64 ? kQpb / 2 : kQpb), G, G == 64>>(kLdsPerCu);
+    return ok;
+}
+template <typename T> int prewarm_part_()
+{
+    const bool ok = prewarm_wave_<T, 16>() & prewarm_wave_<T, 32>() & prewarm_wave_<T, 64>();
+    return ok ? SCCBF_OK : SCCBF_ERR_NO_DEVICE;
+}
+
 template <typename T>
 int solve_impl(const sccbf_params* sp, int64_t A, int32_t M, const T* state, const T* u_ref,
                const T* obs, const uint8_t* obs_type, T* u_out, int32_t* status, T* rows_out,
                void* stream)
 {
-    forget_earlier_errors_();
     KArgs<T> k;
     int rc = fill_args<T>(sp, A, M, k);
     if (rc != SCCBF_OK) return rc;
@@ -344,7 +384,6 @@ int solve_step_impl(const sccbf_params* sp, double max_steer, double dt, int64_t
                     const T* u_ref, const T* obs, const uint8_t* obs_type, T* u_out, int32_t* status,
                     T* beta_out, void* stream)
 {
-    forget_earlier_errors_();
     KArgs<T> k;
     int rc = fill_args<T>(sp, A, M, k);
     if (rc != SCCBF_OK) return rc;
@@ -369,7 +408,6 @@ int solve_sa_impl(const sccbf_params* sp, double dt, int64_t A, int32_t M, const
                   const T* u_ref, const T* obs, const uint8_t* obs_type, T* u_out, int32_t* status,
                   T* rows_out, void* stream)
 {
-    forget_earlier_errors_();
     if (!sp) return SCCBF_ERR_ARG;
     sccbf_params q = *sp;
     q.dynamics = SCCBF_DYN_SADBM;
@@ -390,7 +428,6 @@ template <typename T>
 int partials_impl(const sccbf_params* sp, int64_t A, int32_t M, const T* state, const T* obs,
                   const uint8_t* obs_type, T* out, void* stream)
 {
-    forget_earlier_errors_();
     KArgs<T> k;
     int rc = fill_args<T>(sp, A, M, k);
     if (rc != SCCBF_OK) return rc;
@@ -400,16 +437,15 @@ int partials_impl(const sccbf_params* sp, int64_t A, int32_t M, const T* state, 
     k.u_out = nullptr; k.status = nullptr; k.rows_out = out;
     const long long blocks = (A * M + kBlock - 1) / kBlock;
     if (blocks > 0x7fffffffLL) return SCCBF_ERR_ARG;
-    hipLaunchKernelGGL((k_partials<T>), dim3((unsigned)blocks), dim3(kBlock), 0,
+    launch_((k_partials<T>), dim3((unsigned)blocks), dim3(kBlock), 0,
                        reinterpret_cast<hipStream_t>(stream), k);
-    return hipGetLastError() == hipSuccess ? SCCBF_OK : SCCBF_ERR_LAUNCH;
+    return launched_();
 }
 
 template <typename T>
 int qp_impl(const sccbf_params* sp, int64_t A, int32_t M, const T* rows, const T* u_nom,
             T* u_out, int32_t* status, void* stream)
 {
-    forget_earlier_errors_();
     KArgs<T> k;
     sccbf_params q;
     if (!sp) return SCCBF_ERR_ARG;
@@ -442,7 +478,6 @@ template <typename T>
 int nominal_impl(const sccbf_nominal_params* sp, int64_t A, int32_t N, const T* state, const T* traj,
                  int32_t* target_idx, T* pid_state, T* u_ref, void* stream)
 {
-    forget_earlier_errors_();
     if (!sp || A < 0 || N < 1 || A > 0x7fffffffLL) return SCCBF_ERR_ARG;
     if (A == 0) return SCCBF_OK;
     if (!state || !traj || !target_idx || !u_ref) return SCCBF_ERR_ARG;
@@ -452,25 +487,24 @@ int nominal_impl(const sccbf_nominal_params* sp, int64_t A, int32_t N, const T* 
     k.state = state; k.traj = traj; k.target_idx = target_idx; k.pid_state = pid_state; k.u_ref = u_ref;
     const long long per_block = kNomBlock / kNomLanes;
     const long long blocks = (A + per_block - 1) / per_block;
-    hipLaunchKernelGGL((k_nominal<T>), dim3((unsigned)blocks), dim3(kNomBlock), 0,
+    launch_((k_nominal<T>), dim3((unsigned)blocks), dim3(kNomBlock), 0,
                        reinterpret_cast<hipStream_t>(stream), k);
-    return hipGetLastError() == hipSuccess ? SCCBF_OK : SCCBF_ERR_LAUNCH;
+    return launched_();
 }
 
 template <typename T>
 int vehicle_step_impl(int64_t A, T* state, const T* u, double lr, double lf, double max_steer, double dt,
                       T* beta_out, void* stream)
 {
-    forget_earlier_errors_();
     if (A < 0 || A > 0x7fffffffLL || !(lr > 0.0) || !(lf + lr > 0.0) || !(max_steer >= 0.0) || !std::isfinite(dt))
         return SCCBF_ERR_ARG;
     if (A == 0) return SCCBF_OK;
     if (!state || !u) return SCCBF_ERR_ARG;
     const long long blocks = (A + kBlock - 1) / kBlock;
-    hipLaunchKernelGGL((k_vehicle_step<T>), dim3((unsigned)blocks), dim3(kBlock), 0,
+    launch_((k_vehicle_step<T>), dim3((unsigned)blocks), dim3(kBlock), 0,
                        reinterpret_cast<hipStream_t>(stream), (long long)A, state, u,
                        (T)(lr / (lf + lr)), (T)(1.0 / lr), (T)max_steer, (T)dt, beta_out);
-    return hipGetLastError() == hipSuccess ? SCCBF_OK : SCCBF_ERR_LAUNCH;
+    return launched_();
 }
 
 template <typename T, int RPL, int G>
@@ -479,9 +513,9 @@ int launch_rollout(const RArgs<T>& r, bool ext, hipStream_t s)
     const long long per_block = kBlock / G;
     const long long blocks = (r.f.A + per_block - 1) / per_block;
     if (blocks > 0x7fffffffLL) return SCCBF_ERR_ARG;
-    if (ext) hipLaunchKernelGGL((k_rollout<T, RPL, true, G>), dim3((unsigned)blocks), dim3(kBlock), 0, s, r);
-    else hipLaunchKernelGGL((k_rollout<T, RPL, false, G>), dim3((unsigned)blocks), dim3(kBlock), 0, s, r);
-    return hipGetLastError() == hipSuccess ? SCCBF_OK : SCCBF_ERR_LAUNCH;
+    if (ext) launch_((k_rollout<T, RPL, true, G>), dim3((unsigned)blocks), dim3(kBlock), 0, s, r);
+    else launch_((k_rollout<T, RPL, false, G>), dim3((unsigned)blocks), dim3(kBlock), 0, s, r);
+    return launched_();
 }
 
 template <typename T>
@@ -490,7 +524,6 @@ int rollout_impl(const sccbf_params* sp, const sccbf_nominal_params* np, const s
                  T* slip, const T* obs, const uint8_t* obs_type, T* h_min, int32_t* n_active,
                  int32_t* n_infeasible, T* trace, void* stream)
 {
-    forget_earlier_errors_();
     if (!np || !rp) return SCCBF_ERR_ARG;
     RArgs<T> r;
     int rc = fill_args<T>(sp, A, M, r.f);
@@ -544,24 +577,22 @@ template <typename T>
 int vehicle_step_kin_impl(int64_t A, T* state, const T* u, int32_t mode, double L, double max_steer, double dt,
                           void* stream)
 {
-    forget_earlier_errors_();
     if (A < 0 || A > 0x7fffffffLL || !(max_steer >= 0.0) || !std::isfinite(dt)) return SCCBF_ERR_ARG;
     if (mode != SCCBF_STEP_KIN_ACC && mode != SCCBF_STEP_KIN_VEL && mode != SCCBF_STEP_UNICYCLE) return SCCBF_ERR_ARG;
     if (mode != SCCBF_STEP_UNICYCLE && !(L > 0.0)) return SCCBF_ERR_ARG;
     if (A == 0) return SCCBF_OK;
     if (!state || !u) return SCCBF_ERR_ARG;
     const long long blocks = (A + kBlock - 1) / kBlock;
-    hipLaunchKernelGGL((k_vehicle_step_kin<T>), dim3((unsigned)blocks), dim3(kBlock), 0,
+    launch_((k_vehicle_step_kin<T>), dim3((unsigned)blocks), dim3(kBlock), 0,
                        reinterpret_cast<hipStream_t>(stream), (long long)A, state, u, (int)mode,
                        (T)(L > 0.0 ? 1.0 / L : 0.0), (T)max_steer, (T)dt);
-    return hipGetLastError() == hipSuccess ? SCCBF_OK : SCCBF_ERR_LAUNCH;
+    return launched_();
 }
 
 template <typename T>
 int ingest_impl(int64_t A, int32_t M, const T* bbox, const uint8_t* kind, double buffer, uint32_t flags,
                 T* obs, void* stream)
 {
-    forget_earlier_errors_();
     if (A < 0 || M < 0 || A > 0x7fffffffLL || M > SCCBF_MAX_ROWS || !std::isfinite(buffer)) return SCCBF_ERR_ARG;
     if (flags & ~(SCCBF_FLAG_TYPE_PER_AGENT | SCCBF_FLAG_OBS_TILED)) return SCCBF_ERR_ARG;
     if (A == 0 || M == 0) return SCCBF_OK;
@@ -570,15 +601,14 @@ int ingest_impl(int64_t A, int32_t M, const T* bbox, const uint8_t* kind, double
     k.A = A; k.M = M; k.flags = flags; k.bbox = bbox; k.kind = kind; k.buffer = (T)buffer; k.obs = obs;
     const long long blocks = (A * M + kBlock - 1) / kBlock;
     if (blocks > 0x7fffffffLL) return SCCBF_ERR_ARG;
-    hipLaunchKernelGGL((k_ingest<T>), dim3((unsigned)blocks), dim3(kBlock), 0,
+    launch_((k_ingest<T>), dim3((unsigned)blocks), dim3(kBlock), 0,
                        reinterpret_cast<hipStream_t>(stream), k);
-    return hipGetLastError() == hipSuccess ? SCCBF_OK : SCCBF_ERR_LAUNCH;
+    return launched_();
 }
 
 template <typename T>
 int prepare_impl(int64_t A, int32_t M, T* obs, uint8_t* obs_type, uint32_t flags, void* stream)
 {
-    forget_earlier_errors_();
     if (A < 0 || M < 0 || A > 0x7fffffffLL || M > SCCBF_MAX_ROWS) return SCCBF_ERR_ARG;
     if (flags & ~(SCCBF_FLAG_TYPE_PER_AGENT | SCCBF_FLAG_OBS_TILED | SCCBF_FLAG_OBS_SHARED)) return SCCBF_ERR_ARG;
     if ((flags & SCCBF_FLAG_OBS_SHARED) && (flags & (SCCBF_FLAG_OBS_TILED | SCCBF_FLAG_TYPE_PER_AGENT)))
@@ -591,17 +621,17 @@ int prepare_impl(int64_t A, int32_t M, T* obs, uint8_t* obs_type, uint32_t flags
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const long long blocks = (k.A * M + kBlock - 1) / kBlock;
     if (blocks > 0x7fffffffLL) return SCCBF_ERR_ARG;
-    hipLaunchKernelGGL((k_prepare_obs<T>), dim3((unsigned)blocks), dim3(kBlock), 0, st, k);
+    launch_((k_prepare_obs<T>), dim3((unsigned)blocks), dim3(kBlock), 0, st, k);
+    if (launched_() != SCCBF_OK) return SCCBF_ERR_LAUNCH;  // the kinds are rewritten only over converted slots
     const long long n = (flags & SCCBF_FLAG_TYPE_PER_AGENT) ? (long long)M * A : M;
-    hipLaunchKernelGGL(k_prepare_types, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, n, obs_type);
-    return hipGetLastError() == hipSuccess ? SCCBF_OK : SCCBF_ERR_LAUNCH;
+    launch_(k_prepare_types, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, n, obs_type);
+    return launched_();
 }
 
 template <typename T>
 int lane_fit_impl(int64_t A, int32_t K, int32_t degree, const T* px, const T* py, const T* sigma, double buffer,
                   int32_t m, int32_t M, uint32_t flags, T* obs, void* stream)
 {
-    forget_earlier_errors_();
     if (A < 0 || A > 0x7fffffffLL || K < 1 || degree < 0 || degree > 3 || !std::isfinite(buffer)) return SCCBF_ERR_ARG;
     if (M < 1 || M > SCCBF_MAX_ROWS || m < 0 || m >= M) return SCCBF_ERR_ARG;
     if (flags & ~SCCBF_FLAG_OBS_TILED) return SCCBF_ERR_ARG;
@@ -619,10 +649,10 @@ int lane_fit_impl(int64_t A, int32_t K, int32_t degree, const T* px, const T* py
         const long long per_block = kBlock / G;
         const dim3 grid((unsigned)((A + per_block - 1) / per_block)), block(kBlock);
         switch (degree) {
-        case 0: hipLaunchKernelGGL((k_lane_fit<T, 1, G, H>), grid, block, 0, st, k); break;
-        case 1: hipLaunchKernelGGL((k_lane_fit<T, 2, G, H>), grid, block, 0, st, k); break;
-        case 2: hipLaunchKernelGGL((k_lane_fit<T, 3, G, H>), grid, block, 0, st, k); break;
-        default: hipLaunchKernelGGL((k_lane_fit<T, 4, G, H>), grid, block, 0, st, k); break;
+        case 0: launch_((k_lane_fit<T, 1, G, H>), grid, block, 0, st, k); break;
+        case 1: launch_((k_lane_fit<T, 2, G, H>), grid, block, 0, st, k); break;
+        case 2: launch_((k_lane_fit<T, 3, G, H>), grid, block, 0, st, k); break;
+        default: launch_((k_lane_fit<T, 4, G, H>), grid, block, 0, st, k); break;
         }
     };
     using std::integral_constant;
@@ -631,7 +661,7 @@ int lane_fit_impl(int64_t A, int32_t K, int32_t degree, const T* px, const T* py
     else if (K <= 64) launch(integral_constant<int, 4>{}, integral_constant<int, 16>{});
     else if (sizeof(T) == 4) launch(integral_constant<int, 4>{}, integral_constant<int, 0>{});
     else launch(integral_constant<int, 1>{}, integral_constant<int, 0>{});
-    return hipGetLastError() == hipSuccess ? SCCBF_OK : SCCBF_ERR_LAUNCH;
+    return launched_();
 }
 
 
@@ -643,9 +673,9 @@ int launch_group_batches(const KArgs<T>& k, const sccbf_batch* table, int K, lon
     const long long bx = (a_max + per_block - 1) / per_block;
     if (bx > 0x7fffffffLL) return SCCBF_ERR_ARG;
     const dim3 grid((unsigned)bx, (unsigned)K);
-    if (nt) hipLaunchKernelGGL((k_group_batches<T, G, RPL, true>), grid, dim3(kBlock), 0, s, table, k.M, k.flags, k);
-    else hipLaunchKernelGGL((k_group_batches<T, G, RPL, false>), grid, dim3(kBlock), 0, s, table, k.M, k.flags, k);
-    return hipGetLastError() == hipSuccess ? SCCBF_OK : SCCBF_ERR_LAUNCH;
+    if (nt) launch_((k_group_batches<T, G, RPL, true>), grid, dim3(kBlock), 0, s, table, k.M, k.flags, k);
+    else launch_((k_group_batches<T, G, RPL, false>), grid, dim3(kBlock), 0, s, table, k.M, k.flags, k);
+    return launched_();
 }
 
 template <typename T, int G>
@@ -667,9 +697,9 @@ int launch_wave_batches_shape(const KArgs<T>& k, const sccbf_batch* table, int K
     const long long bx = wave_blocks<QPB, PAIRED>(a_max);
     if (bx > 0x7fffffffLL) return SCCBF_ERR_ARG;
     if (!grant_lds<k_wave_batches<T, QPB, G, PAIRED>>(lds)) return SCCBF_ERR_VARIANT;
-    hipLaunchKernelGGL((k_wave_batches<T, QPB, G, PAIRED>), dim3((unsigned)bx, (unsigned)K), dim3(QPB * G), lds, s, table,
+    launch_((k_wave_batches<T, QPB, G, PAIRED>), dim3((unsigned)bx, (unsigned)K), dim3(QPB * G), lds, s, table,
                        k.M, k.flags, k);
-    return hipGetLastError() == hipSuccess ? SCCBF_OK : SCCBF_ERR_LAUNCH;
+    return launched_();
 }
 
 template <typename T, int G>
@@ -700,8 +730,8 @@ int batches_launch(const sccbf_params* sp, int32_t K, int32_t M, int64_t a_max, 
     if (M == 0) {
         const long long bx = (a_max + kBlock - 1) / kBlock;
         if (bx > 0x7fffffffLL) return SCCBF_ERR_ARG;
-        hipLaunchKernelGGL((k_passthrough_batches<T>), dim3((unsigned)bx, (unsigned)K), dim3(kBlock), 0, s, table, k);
-        return hipGetLastError() == hipSuccess ? SCCBF_OK : SCCBF_ERR_LAUNCH;
+        launch_((k_passthrough_batches<T>), dim3((unsigned)bx, (unsigned)K), dim3(kBlock), 0, s, table, k);
+        return launched_();
     }
     // lanes per QP as for one launch over all the agents (the batches fill the GPU together)
     const double total = (double)a_max * K;
@@ -727,7 +757,6 @@ template <typename T>
 int solve_batches_impl(const sccbf_params* sp, int32_t K, int32_t M, int64_t a_max, const sccbf_batch* table,
                        void* stream)
 {
-    forget_earlier_errors_();
     return batches_launch<T>(sp, K, M, a_max, table, stream);
 }
 
@@ -771,6 +800,14 @@ __global__ __launch_bounds__(kFillBatches * 8) void k_table_fill(sccbf_batch* ds
     reinterpret_cast<unsigned long long*>(dst)[i] = f[i % 8];
 }
 
+template <typename T, int G> bool prewarm_wave_batches_()
+{
+    constexpr int kQpb = WaveShape<T, G>::kQpb;
+    bool ok = grant_lds<k_wave_batches<T, kQpb, G, false>>(kLdsPerCu);
+    if (G == 64) ok &= grant_lds<k_wave_batches<T, (G == 64 ? kQpb / 2 : kQpb), G, G == 64>>(kLdsPerCu);
+    return ok;
+}
+
 template <typename T>
 int solve_batches_static_impl(const sccbf_params* sp, int32_t K, int32_t M, const sccbf_batch* host, void* stream)
 {
@@ -795,8 +832,8 @@ int solve_batches_static_impl(const sccbf_params* sp, int32_t K, int32_t M, cons
         BatchChunk c;
         const int n = K - at < kFillBatches ? K - at : kFillBatches;
         for (int i = 0; i < kFillBatches; ++i) c.b[i] = host[at + (i < n ? i : 0)];
-        hipLaunchKernelGGL(k_table_fill, dim3(1), dim3(kFillBatches * 8), 0, s, table + at, c, n);
-        if (hipGetLastError() != hipSuccess) return SCCBF_ERR_LAUNCH;
+        launch_(k_table_fill, dim3(1), dim3(kFillBatches * 8), 0, s, table + at, c, n);
+        if (launched_() != SCCBF_OK) return SCCBF_ERR_LAUNCH;
     }
     return batches_launch<T>(sp, K, M, a_max, table, stream);
 }
@@ -822,7 +859,6 @@ int sccbf_solve_batches_f64(const sccbf_params* p, int32_t K, int32_t M, int64_t
 int sccbf_solve_batches_static(const sccbf_params* p, int32_t scalar_bytes, int32_t K, int32_t M,
                                const sccbf_batch* batches, void* stream)
 {
-    forget_earlier_errors_();
     if (scalar_bytes == 4) return solve_batches_static_impl<float>(p, K, M, batches, stream);
     if (scalar_bytes == 8) return solve_batches_static_impl<double>(p, K, M, batches, stream);
     return SCCBF_ERR_ARG;
@@ -897,6 +933,31 @@ int sccbf_solve_step_f64(const sccbf_params* p, double max_steer, double dt, int
 
 #if SCCBF_HAS_F32
 int sccbf_version(void) { return SCCBF_VERSION; }
+#endif
+
+// one piece of sccbf_prewarm per part of the library (the parts are separate objects of this one source)
+extern "C" __attribute__((visibility("hidden"))) int sccbf_prewarm_f32_(void);
+extern "C" __attribute__((visibility("hidden"))) int sccbf_prewarm_f64_(void);
+extern "C" __attribute__((visibility("hidden"))) int sccbf_prewarm_batches_(void);
+#if SCCBF_HAS_F32
+int sccbf_prewarm_f32_(void) { return prewarm_part_<float>(); }
+int sccbf_prewarm(void)
+{
+    const int a = sccbf_prewarm_f32_(), b = sccbf_prewarm_f64_(), c = sccbf_prewarm_batches_();
+    return a != SCCBF_OK ? a : (b != SCCBF_OK ? b : c);
+}
+#endif
+#if SCCBF_HAS_F64
+int sccbf_prewarm_f64_(void) { return prewarm_part_<double>(); }
+#endif
+#if SCCBF_HAS_BATCHES
+int sccbf_prewarm_batches_(void)
+{
+    const bool ok = prewarm_wave_batches_<float, 16>() & prewarm_wave_batches_<float, 32>() & prewarm_wave_batches_<float, 64>() &
+                    prewarm_wave_batches_<double, 16>() & prewarm_wave_batches_<double, 32>() &
+                    prewarm_wave_batches_<double, 64>();
+    return ok && static_table_() ? SCCBF_OK : SCCBF_ERR_NO_DEVICE;
+}
 #endif
 
 #if SCCBF_HAS_F32

@@ -147,6 +147,11 @@ class ClosedLoop:
         self.beta = torch.empty((A,), dtype=ty, device=dev)
         # steer-rate model (SADBM_CBF_2DS): the filter integrates its own slip angle; the cones follow it
         self.slip = torch.zeros((A, 2), dtype=ty, device=dev) if cbf.params.dynamics == _lib.DYN_SADBM else None
+        if self.slip is not None and bool((obs_type == _lib.OBS_CONE_PREP).any().item()):
+            # every cone of this model follows the agent's slip angle (reference cbf/cbf.py:424-427); a prepared cone
+            # holds the velocity resolved with the beta it was prepared with and would silently stay there
+            raise ValueError("ClosedLoop with the steer-rate model: prepared collision cones (kind 5) cannot follow the "
+                             "agent's slip angle; keep the cones as written (kind 1)")
 
     def _check_inputs(self):
         """Shapes, dtypes, device and contiguity of every tensor the kernels index: a tensor built

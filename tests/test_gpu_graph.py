@@ -136,3 +136,55 @@ def test_rollout_replays_equal_eager():
             assert torch.equal(loop.state, ref_state), replay
             for k in ref:
                 assert torch.equal(out[k], ref[k]), (replay, k)
+
+
+def test_prewarm_lets_a_first_long_list_launch_be_captured():
+    """A fresh process whose FIRST launch with rows in LDS only (300 rows: tables beyond 64 KB per workgroup) and
+    whose first sccbf_solve_batches_static happen inside stream capture: refused without sccbf_prewarm, fine after it,
+    and the replays give the eager answers."""
+    import subprocess
+    import sys
+    code = r'''
+import numpy as np, torch, sys
+sys.path.insert(0, %r)
+from sccav_cbf_amd import _lib, scenarios
+from sccav_cbf_amd.batched import BatchedCBF, BatchTable, prewarm
+dev = torch.device("cuda:0")
+w = scenarios.monte_carlo(200, 150, 150, 3, nominal="uniform")
+t = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in w.items()}
+t = {k: (v.float().contiguous() if v.dtype.is_floating_point else v) for k, v in t.items()}
+t["u_out"] = torch.empty_like(t["u_ref"]); t["status"] = torch.empty((200,), dtype=torch.int32, device=dev)
+flt = BatchedCBF(alpha=1.0, R=np.diag([0.5, 0.5]))
+table = BatchTable([t])
+stream = torch.cuda.Stream(dev)
+def capture():
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=stream):
+        flt.solve(t["state"], t["u_ref"], t["obs"], t["obs_type"], u_out=t["u_out"], status=t["status"])
+        flt.solve_batches_static(table)
+    return g
+with torch.cuda.stream(stream):
+    if "--no-prewarm" in sys.argv:
+        try:
+            capture()
+        except Exception as e:
+            print("REFUSED", type(e).__name__)
+            sys.exit(0)
+        print("CAPTURED WITHOUT PREWARM")
+        sys.exit(0)
+    prewarm()
+    g = capture()
+    for _ in range(3):
+        t["u_out"].fill_(float("nan")); t["status"].fill_(-1)
+        torch.cuda.synchronize()
+        g.replay()
+        torch.cuda.synchronize()
+        got = (t["u_out"].clone(), t["status"].clone())
+        u, st = flt.solve(t["state"], t["u_ref"], t["obs"], t["obs_type"])
+        torch.cuda.synchronize()
+        assert torch.equal(got[0], u) and torch.equal(got[1], st)
+print("OK")
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SCCBF_NO_REBUILD="1")
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert res.returncode == 0 and res.stdout.strip().endswith("OK"), res.stdout[-500:] + res.stderr[-1500:]

@@ -220,3 +220,27 @@ def test_one_wavefront_per_qp_for_the_other_models(oracle, dyn, M, lanes, dtype)
     if dyn == "sadbm":
         ok = (sg == so) & ((so != 0) | both)     # the slip follows the input: the agents whose inputs are compared
         assert np.abs(sl.double().cpu().numpy() - so_slip)[ok].max() <= (1e-9 if dtype == torch.float64 else 1e-4)
+
+
+def test_prepared_cones_are_refused_where_they_would_silently_stop_following_the_slip_angle():
+    """SADBM hands every cone the agent's slip angle after each solve (reference cbf/cbf.py:424-427); a prepared cone
+    keeps the beta it was prepared with: the front ends say so instead of computing other rows than the reference's."""
+    from sccav_cbf_amd import scenarios
+    from sccav_cbf_amd.batched import BatchedCBF
+    from sccav_cbf_amd.nominal import ClosedLoop
+    dev = torch.device("cuda:0")
+    w = scenarios.config4(A=64, nominal="uniform")
+    obs = torch.from_numpy(w["obs"]).to(dev)
+    ty = torch.from_numpy(w["obs_type"]).to(dev)
+    state = torch.from_numpy(w["state"]).to(dev)
+    sa = BatchedCBF(dynamics="sadbm")
+    with pytest.raises(ValueError, match="frozen_cone_beta"):
+        sa.prepare_obs(obs.clone(), ty.clone())
+    o2, t2 = sa.prepare_obs(obs.clone(), ty.clone(), frozen_cone_beta=True)      # said so: allowed
+    assert set(t2.cpu().tolist()) == {4, 5}
+    with pytest.raises(ValueError, match="prepared collision cones"):
+        ClosedLoop(sa, None, None, state.clone(), o2, t2, dt=0.1)
+    BatchedCBF(dynamics="dbm").prepare_obs(obs.clone(), ty.clone())             # the bicycle models take them
+    only_ellipses = ty.clone()
+    only_ellipses[ty == 1] = 255
+    sa.prepare_obs(obs.clone(), only_ellipses)                                   # no cones: nothing to refuse

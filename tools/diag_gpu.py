@@ -1,6 +1,6 @@
 """Diagnostic (not collected by pytest): every kernel variant vs the oracle, with statistics.
 
-    python tests/diag_gpu.py [A]
+    python tools/diag_gpu.py [A]
 """
 import os
 import sys

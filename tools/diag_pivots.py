@@ -1,7 +1,7 @@
 """How many pivots does the active-set iteration take on the bench batch?  A numpy restatement of the device
 iteration (most violated row first, the 1-D problem along its line bounded by the two stored rows) on the oracle's
 rows of one configuration-4 batch: pivots per QP, and per group of QPs that iterate together in a wavefront
-(16 with four lanes per QP).  CPU only: python tests/diag_pivots.py"""
+(16 with four lanes per QP).  CPU only: python tools/diag_pivots.py"""
 import os
 import sys
 
