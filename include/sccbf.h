@@ -39,6 +39,7 @@
  *   SCCBF_OBS_ELLIPSE  cx, cy, a, b, theta_o, vx, vy, -      (a, b include buffer)
  *   SCCBF_OBS_CONE     cx, cy, theta_o, v_o, a, beta, -, -   (a includes buffer)
  *   SCCBF_OBS_LANE     c0, c1, c2, c3, buffer, -, -, -       y = c0+c1 x+c2 x^2+c3 x^3
+ *   SCCBF_OBS_LANE6    c0, c1, c2, c3, c4, c5, c6, buffer    the same barrier for a polynomial of degree up to 6
  *   SCCBF_OBS_RADIAL   cx, cy, a, b, cdot_x, cdot_y, kv, -
  *   SCCBF_OBS_EMPTY    ignored (row 0.u >= -1, always satisfied)
  * Prepared kinds: the same obstacles with everything that does not depend on the agent already
@@ -77,6 +78,7 @@ extern "C" {
 #define SCCBF_OBS_CONE_PREP 5    /* CollisionCone2D, cbf/obstacles.py:401-502, obstacle velocity resolved */
 #define SCCBF_OBS_ELLIPSE_BOX 6  /* Ellipse2D.from_bounding_box, cbf/obstacles.py:320-331, made from the box per tick */
 #define SCCBF_OBS_CONE_BOX 7     /* CollisionCone2D.from_bounding_box, cbf/obstacles.py:534-543, likewise */
+#define SCCBF_OBS_LANE6 8        /* PolyLane with more than four coefficients, cbf/obstacles.py:578-593 */
 #define SCCBF_OBS_EMPTY 255
 
 /* vehicle model */

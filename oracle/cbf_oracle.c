@@ -37,6 +37,7 @@
 #define ORC_OBS_CONE_PREP 5
 #define ORC_OBS_ELLIPSE_BOX 6
 #define ORC_OBS_CONE_BOX 7
+#define ORC_OBS_LANE6 8
 #define ORC_OBS_EMPTY 255
 
 #define ORC_DYN_DBM 0
@@ -201,6 +202,66 @@ double orc_lane_closest_x(const double c[4], double px, double py)
     return x;
 }
 
+/* The same for a polynomial of any degree below ORC_LANE_MAX_COEFFS coefficients: PolyLane takes a coefficient
+ * array of any length (cbf/obstacles.py:578-593, numpy Polynomial and its two derivatives). */
+#define ORC_LANE_MAX_COEFFS 7
+static void orc_polyn(const double* c, int n, double x, double* f, double* df, double* ddf)
+{
+    double a = 0.0, b = 0.0, d = 0.0;
+    for (int k = n - 1; k >= 0; --k) a = c[k] + x * a;
+    for (int k = n - 1; k >= 1; --k) b = k * c[k] + x * b;
+    for (int k = n - 1; k >= 2; --k) d = (double)(k * (k - 1)) * c[k] + x * d;
+    *f = a;
+    *df = b;
+    *ddf = d;
+}
+
+double orc_lane_closest_x_n(const double* c, int n, double px, double py)
+{
+    double x = px;
+    for (int it = 0; it < ORC_LANE_ITERS; ++it) {
+        double f, df, ddf;
+        orc_polyn(c, n, x, &f, &df, &ddf);
+        double rr = f - py;
+        double g0 = (x - px) * (x - px) + rr * rr;
+        double g1 = 2.0 * (x - px) + 2.0 * rr * df;
+        double g2 = 2.0 * (1.0 + df * df + rr * ddf);
+        double step = (g2 > 1e-12) ? -g1 / g2 : -g1 / (fabs(g2) + 1.0);
+        if (step == 0.0) break;
+        double xn = x + step;
+        double glim = g0 * (1.0 + 8.0 * 2.220446049250313e-16);
+        for (int k = 0; k < ORC_LANE_HALVINGS; ++k) {
+            double fn, dfn, ddfn;
+            orc_polyn(c, n, xn, &fn, &dfn, &ddfn);
+            double gn = (xn - px) * (xn - px) + (fn - py) * (fn - py);
+            /* a step already below the tolerance is taken as it is: the two distances differ by less than
+             * their own rounding, and halving the step on that noise would leave x one step short */
+            if (gn <= glim || fabs(step) <= 1e-8 * (1.0 + fabs(x))) break;
+            step *= 0.5;
+            xn = x + step;
+        }
+        x = xn;
+        if (fabs(step) <= 1e-8 * (1.0 + fabs(x))) break;
+    }
+    return x;
+}
+
+/* A lane of degree up to 6: o = c0 ... c6, buffer.  Same formulas as orc_lane below. */
+static void orc_lane6(const double s[4], const double o[8], double eps, orc_partials* r)
+{
+    double cx = orc_lane_closest_x_n(o, ORC_LANE_MAX_COEFFS, s[0], s[1]);
+    double g, dg, ddg;
+    orc_polyn(o, ORC_LANE_MAX_COEFFS, cx, &g, &dg, &ddg);
+    double eta = 1.0 + dg * ddg + dg * dg - s[1] * ddg;
+    if (fabs(eta) < eps) eta = eps;
+    r->h = (cx - s[0]) * (cx - s[0]) + (g - s[1]) * (g - s[1]) - o[7];
+    r->hx = (2.0 / eta) * ((s[0] - cx) * (eta - 1.0) - (s[1] - g) * dg);
+    r->hy = (2.0 / eta) * (-(s[0] - cx) * dg + (s[1] - g) * (eta - dg * dg));
+    r->hth = 0.0;
+    r->hv = 0.0;
+    r->ht = 0.0;
+}
+
 /* PolyLane.update/evaluate/dx/dy, cbf/obstacles.py:620-636, 607-612, 681-689.
  * o = c0, c1, c2, c3, buffer.  eta and the un-squared buffer are as written. */
 static void orc_lane(const double s[4], const double o[8], double eps, orc_partials* r)
@@ -245,6 +306,7 @@ int orc_barrier(int type, const double s[4], const double o_in[8], double zero_t
     case ORC_OBS_ELLIPSE: orc_ellipse(s, o, r); return 1;
     case ORC_OBS_CONE: orc_cone(s, o, zero_tol, r); return 1;
     case ORC_OBS_LANE: orc_lane(s, o, zero_tol, r); return 1;
+    case ORC_OBS_LANE6: orc_lane6(s, o, zero_tol, r); return 1;
     case ORC_OBS_RADIAL: orc_radial(s, o, r); return 1;
     case ORC_OBS_ELLIPSE_PREP: orc_ellipse_prep(s, o, r); return 1;
     case ORC_OBS_CONE_PREP: orc_cone_prep(s, o, zero_tol, r); return 1;

@@ -14,6 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "liboracle.so")
 
 OBS_ELLIPSE, OBS_CONE, OBS_LANE, OBS_RADIAL, OBS_EMPTY = 0, 1, 2, 3, 255
+OBS_LANE6 = 8   # a lane polynomial of degree up to 6: c0 ... c6, buffer
 OBS_ELLIPSE_PREP, OBS_CONE_PREP = 4, 5
 OBS_ELLIPSE_BOX, OBS_CONE_BOX = 6, 7   # the slot is the bounding box itself: x, y, extent x, y | yaw, speed, buffer
 DYN_DBM, DYN_KBM, DYN_DUM, DYN_SADBM = 0, 1, 2, 3
@@ -78,6 +79,8 @@ def lib():
         L.orc_row.argtypes = [C.POINTER(Params), dp, C.POINTER(Partials), dp]
         L.orc_lane_closest_x.restype = C.c_double
         L.orc_lane_closest_x.argtypes = [dp, C.c_double, C.c_double]
+        L.orc_lane_closest_x_n.restype = C.c_double
+        L.orc_lane_closest_x_n.argtypes = [dp, C.c_int, C.c_double, C.c_double]
         L.orc_vehicle_step.restype = C.c_double
         L.orc_vehicle_step.argtypes = [dp] + [C.c_double] * 6
         L.orc_stanley.restype = C.c_double
@@ -188,8 +191,14 @@ def row(params, s, partials):
 
 
 def lane_closest_x(coeffs, px, py):
-    c = np.zeros(4)
+    """Abscissa of the curve point nearest to (px, py); up to 4 coefficients through the cubic form, up to 7 through
+    the general one."""
     cc = _f64(coeffs).reshape(-1)
+    if cc.size > 4:
+        c = np.zeros(7)
+        c[:cc.size] = cc
+        return lib().orc_lane_closest_x_n(_dp(c), 7, float(px), float(py))
+    c = np.zeros(4)
     c[:cc.size] = cc
     return lib().orc_lane_closest_x(_dp(c), float(px), float(py))
 

@@ -13,6 +13,7 @@ ABI_VERSION = 300   # SCCBF_VERSION of include/sccbf.h this binding was written 
 OBS_ELLIPSE, OBS_CONE, OBS_LANE, OBS_RADIAL, OBS_EMPTY = 0, 1, 2, 3, 255
 OBS_ELLIPSE_PREP, OBS_CONE_PREP = 4, 5   # the same obstacles, per-obstacle constants already evaluated
 OBS_ELLIPSE_BOX, OBS_CONE_BOX = 6, 7     # the slot is the obstacle's bounding box + buffer, the filter makes the obstacle
+OBS_LANE6 = 8                            # a lane polynomial of degree up to 6: c0 ... c6, buffer
 DYN_DBM, DYN_KBM, DYN_DUM, DYN_SADBM = 0, 1, 2, 3
 STATUS_OPTIMAL, STATUS_INFEASIBLE, STATUS_NONFINITE = 0, 1, 2
 FLAG_OBS_SHARED, FLAG_TYPE_PER_AGENT, FLAG_SLIP_IO, FLAG_OBS_TILED = 1, 2, 4, 8

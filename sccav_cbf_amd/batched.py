@@ -359,6 +359,12 @@ def lane_slots(c0, c1=0.0, c2=0.0, c3=0.0, buffer=1.5):
     return _stack8(c0, c1, c2, c3, buffer, 0.0, 0.0, 0.0)
 
 
+def lane6_slots(c, buffer=1.5):
+    """SCCBF_OBS_LANE6 slots from up to seven coefficients c = (c0, c1, ...), y = c0 + c1 x + ... + c6 x^6."""
+    c = list(c) + [0.0] * (7 - len(c))
+    return _stack8(*c[:7], buffer)
+
+
 def radial_slots(cx, cy, a, b, cdot_x=0.0, cdot_y=0.0, kv=1.0):
     return _stack8(cx, cy, a, b, cdot_x, cdot_y, kv, 0.0)
 

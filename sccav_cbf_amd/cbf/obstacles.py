@@ -26,6 +26,7 @@ from .geometry import Rotation
 from .utils import ZERO_TOL  # noqa: F401  (re-exported like the reference module)
 
 OBS_ELLIPSE, OBS_CONE, OBS_LANE, OBS_RADIAL = 0, 1, 2, 3
+OBS_LANE6 = 8
 
 
 class Obstacle2DTypes(enum.Enum):
@@ -317,8 +318,9 @@ class CollisionCone2D(Obstacle2DBase, _Buffered):
 
 
 class PolyLane(Obstacle2DBase):
-    """Polynomial lane boundary y = c0 + c1 x + c2 x^2 + c3 x^3; the barrier is the squared
-    distance to the nearest curve point minus `buffer` (reference cbf/obstacles.py:545-773)."""
+    """Polynomial lane boundary y = c0 + c1 x + ... (up to degree 6; the reference takes a coefficient array of any
+    length, cbf/obstacles.py:578-593); the barrier is the squared distance to the nearest curve point minus `buffer`
+    (reference cbf/obstacles.py:545-773)."""
     type = Obstacle2DTypes.POLY_LANE
 
     def __init__(self, coefficients, s=None, s_obs=None, buffer=1.50, **kwargs):
@@ -332,11 +334,11 @@ class PolyLane(Obstacle2DBase):
         self.buffer = buffer
 
     def update_coeffs(self, coefficients):
-        """coefficients = [a0, a1, a2, ...] of f(x) = a0 + a1 x + a2 x^2 + ... (degree <= 3
-        on the GPU path)."""
+        """coefficients = [a0, a1, a2, ...] of f(x) = a0 + a1 x + a2 x^2 + ... (degree <= 6: an obstacle slot
+        holds seven coefficients and the buffer)."""
         c = np.asarray(coefficients, dtype=np.float64).reshape(-1)
-        if c.size > 4 and np.any(c[4:] != 0.0):
-            raise ValueError("PolyLane supports polynomials up to degree 3, got degree %d" % (c.size - 1))
+        if c.size > 7 and np.any(c[7:] != 0.0):
+            raise ValueError("PolyLane supports polynomials up to degree 6, got degree %d" % (c.size - 1))
         self.coeffs = c
         self.order = int(c.size - 1)
 
@@ -344,9 +346,11 @@ class PolyLane(Obstacle2DBase):
         return np.polynomial.polynomial.polyval(x, self.coeffs)
 
     def slot(self):
-        c = np.zeros(4)
-        n = min(4, self.coeffs.size)
+        c = np.zeros(7)
+        n = min(7, self.coeffs.size)
         c[:n] = self.coeffs[:n]
+        if np.any(c[4:] != 0.0):     # degree 4 ... 6: the kind with seven coefficients
+            return OBS_LANE6, [c[0], c[1], c[2], c[3], c[4], c[5], c[6], self.buffer]
         return OBS_LANE, [c[0], c[1], c[2], c[3], self.buffer, 0.0, 0.0, 0.0]
 
     def update(self, s=None, s_obs=None, buffer=None, **kwargs):

@@ -18,18 +18,27 @@ static_assert(sizeof(sccbf_batch) == 64, "one batch record = one 64-byte scalar 
 // This workgroup's batch: its record -> the per-batch fields of the argument block.  False for a record that
 // the kernels must not touch (no agents, more agents than the grid was sized for, or a pointer missing): its
 // workgroups leave.  On entry p.A holds the size the grid was made for.
+// A pointer read from the table is a number as far as the compiler knows; said to be a global address (which a device
+// pointer of the caller's is), the loads and stores through it are global ones, counted by vmcnt alone, and the kernel
+// keeps the counted waits of k_group (as generic "flat" accesses they would all be waited for together).
+template <typename P> __device__ inline P* global_ptr_(const void* p)
+{
+    typedef __attribute__((address_space(1))) P* gptr;
+    return (P*)(gptr)(unsigned long long)p;
+}
+
 template <typename T> __device__ inline bool batch_args_(const sccbf_batch* table, int M, KArgs<T>& p)
 {
     const long long a_max = p.A;
     const sccbf_batch d = table[blockIdx.y];  // uniform over the workgroup: scalar loads
     p.A = d.A;
-    p.state = static_cast<const T*>(d.state);
-    p.u_ref = static_cast<const T*>(d.u_ref);
-    p.obs = static_cast<const T*>(d.obs);
-    p.obs_type = static_cast<const uint8_t*>(d.obs_type);
-    p.u_out = static_cast<T*>(d.u_out);
-    p.status = static_cast<int*>(d.status);
-    p.rows_out = static_cast<T*>(d.rows_out);
+    p.state = global_ptr_<const T>(d.state);
+    p.u_ref = global_ptr_<const T>(d.u_ref);
+    p.obs = global_ptr_<const T>(d.obs);
+    p.obs_type = global_ptr_<const uint8_t>(d.obs_type);
+    p.u_out = global_ptr_<T>(d.u_out);
+    p.status = global_ptr_<int>(d.status);
+    p.rows_out = global_ptr_<T>(d.rows_out);
     const bool slots = M == 0 || (d.obs && d.obs_type);
     return d.A > 0 && d.A <= a_max && d.state && d.u_ref && d.u_out && d.status && slots;
 }
@@ -37,7 +46,7 @@ template <typename T> __device__ inline bool batch_args_(const sccbf_batch* tabl
 // k_group over a table of batches: straight-line code like k_group itself (a loop over several turns per
 // workgroup, for batches larger than the grid, costs 35 registers per lane and three of seven wavefronts per SIMD).
 template <typename T, int G, int RPL, bool NT>
-__global__ __launch_bounds__(kBlock) void k_group_batches(const sccbf_batch* table, int M, unsigned flags,
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kGroupWaves<T, RPL>))) void k_group_batches(const sccbf_batch* table, int M, unsigned flags,
                                                           const KArgs<T> rest)
 {
     KArgs<T> p = rest;

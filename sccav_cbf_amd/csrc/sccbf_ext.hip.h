@@ -49,6 +49,9 @@ __device__ inline void ext_slot_row_(int type, T (&o)[8], const Ego<T>& e, const
         hb = d.hth;  // CollisionCone2D.dbeta, reference cbf/obstacles.py:460-466
         break;
     case SCCBF_OBS_LANE: lane_(e.x, e.y, o, p.zero_tol, d); break;
+#ifndef SCCBF_NO_LANE6
+    case SCCBF_OBS_LANE6: lane6_(e.x, e.y, o, p.zero_tol, d); break;
+#endif
     case SCCBF_OBS_RADIAL: radial_(e.x, e.y, e.v, o, d); break;
     case SCCBF_OBS_ELLIPSE_PREP: ellipse_prep_(e.x, e.y, o, d); break;
     case SCCBF_OBS_CONE_PREP:

@@ -86,7 +86,7 @@ __device__ inline int lane_rows_(const KArgs<T>& p, long long qp, int m0, int dm
             slot_row_(ty, o, e, p, a0, a1, b, h);
             if (p.rows_out && m < M && live)
                 reinterpret_cast<v4*>(p.rows_out)[(long long)m * p.A + qp] = v4{a0, a1, b, h};
-            if (h_min && ty >= 0 && ty <= SCCBF_OBS_CONE_BOX) *h_min = min_(*h_min, h);  // real slots only
+            if (h_min && ty >= 0 && ty <= SCCBF_OBS_LANE6) *h_min = min_(*h_min, h);  // real slots only
         }
         chk += a0 * T(0) + a1 * T(0) + b * T(0);
         to_wspace_(a0, a1, b, e, p, at0[r], at1[r], bt[r]);
@@ -197,11 +197,16 @@ __device__ inline void group_solve_(const KArgs<T>& p, long long qp, int g, cons
     if (g == 0) store_result_(p, qp, QP_ONLY, s.st, s.w0, s.w1, e, ur0, ur1);
 }
 
+// Wavefronts per SIMD the register allocation of a k_group instantiation is held to (at least): the fp64 kernels with up
+// to four rows per lane sit at 126 ... 130 registers, two either side of the 128 that four wavefronts allow, and the
+// allocator finds the two when asked (nothing spilled: tests/test_isa.py); the others are left alone.
+template <typename T, int RPL> constexpr int kGroupWaves = (sizeof(T) == 8 && RPL <= 4) ? 4 : 1;
+
 // The arguments every wave needs before it can issue its first loads come first and one
 // by one: the leading 16 dwords of the kernel arguments are preloaded into SGPRs at wave
 // launch (-amdgpu-kernarg-preload-count), which a by-value struct does not qualify for.
 template <typename T, int G, int RPL, bool QP_ONLY, bool NT>
-__global__ __launch_bounds__(kBlock) void k_group(long long A, const T* obs, const T* state, const T* u_ref,
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kGroupWaves<T, RPL>))) void k_group(long long A, const T* obs, const T* state, const T* u_ref,
                                                   const uint8_t* obs_type, int M, unsigned flags,
                                                   const KArgs<T> rest)
 {

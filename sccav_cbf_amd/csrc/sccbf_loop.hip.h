@@ -562,7 +562,7 @@ void k_rollout(const RArgs<T> a)
                 const int ty = m < p.M ? L.ty[r] : SCCBF_OBS_EMPTY;
                 T a0, a1, b, h;
                 ext_slot_row_(ty, o, e, p, sadbm, sadbm, sl.x, cthb, sthb, sb, a0, a1, b, h);
-                if (ty >= 0 && ty <= SCCBF_OBS_CONE_BOX) hm = min_(hm, h);
+                if (ty >= 0 && ty <= SCCBF_OBS_LANE6) hm = min_(hm, h);
                 chk += a0 * T(0) + a1 * T(0) + b * T(0);
                 to_wspace_(a0, a1, b, e, p, at0[r], at1[r], bt[r]);
             }

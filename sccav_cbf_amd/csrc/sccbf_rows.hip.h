@@ -206,6 +206,68 @@ __device__ inline void lane_(T x, T y, const T o[8], T eps, Partials<T>& r)
     r.ht = T(0);
 }
 
+// A lane polynomial of degree up to 6 (SCCBF_OBS_LANE6: o = c0 ... c6, buffer): PolyLane takes a coefficient array
+// of any length, reference cbf/obstacles.py:578-593.  Its own out-of-line closest-point iteration, so that the cubic
+// one above stays what it is; otherwise the same Newton with halving and the same formulas.
+template <typename T> __device__ inline void poly6_(const T c[7], T x, T& f, T& df, T& ddf)
+{
+    f = c[0] + x * (c[1] + x * (c[2] + x * (c[3] + x * (c[4] + x * (c[5] + x * c[6])))));
+    df = c[1] + x * (T(2) * c[2] + x * (T(3) * c[3] + x * (T(4) * c[4] + x * (T(5) * c[5] + x * (T(6) * c[6])))));
+    ddf = T(2) * c[2] + x * (T(6) * c[3] + x * (T(12) * c[4] + x * (T(20) * c[5] + x * (T(30) * c[6]))));
+}
+
+// Inlined (its loops stay rolled): as a function of its own it needs 24 registers in fp32 and 66 in fp64 below the
+// caller's live ones, which costs the kernels that keep four rows per lane a wavefront per SIMD; inlined it works on
+// the slot's own registers.  The state carried around the loops is kept to x, the step and the distance at x.
+template <typename T>
+__device__ __forceinline__ T lane6_closest_x_(T c0, T c1, T c2, T c3, T c4, T c5, T c6, T px, T py)
+{
+    const T c[7] = {c0, c1, c2, c3, c4, c5, c6};
+    T x = px;
+#pragma nounroll
+    for (int it = 0; it < kLaneIters; ++it) {
+        T f, df, ddf;
+        poly6_(c, x, f, df, ddf);
+        const T rr = f - py;
+        const T g0 = (x - px) * (x - px) + rr * rr;
+        const T g1 = T(2) * (x - px) + T(2) * rr * df;
+        const T g2 = T(2) * (T(1) + df * df + rr * ddf);
+        T step = (g2 > T(1e-12)) ? div_(-g1, g2) : div_(-g1, abs_(g2) + T(1));
+        if (step == T(0)) break;
+#pragma nounroll
+        for (int k = 0; k < kLaneHalvings; ++k) {
+            const T xn = x + step;
+            const T fn = c[0] + xn * (c[1] + xn * (c[2] + xn * (c[3] + xn * (c[4] + xn * (c[5] + xn * c[6])))));
+            const T gn = (xn - px) * (xn - px) + (fn - py) * (fn - py);
+            // a step already below the tolerance is taken as it is: the distances before and after it differ by less
+            // than their own rounding, and halving it on that noise would leave x one step short
+            if (gn <= g0 * (T(1) + T(8) * Lim<T>::eps) || abs_(step) <= Lim<T>::lane_xtol * (T(1) + abs_(x))) break;
+            step *= T(0.5);
+        }
+        x += step;
+        if (abs_(step) <= Lim<T>::lane_xtol * (T(1) + abs_(x))) break;
+    }
+    return x;
+}
+
+template <typename T>
+__device__ inline void lane6_(T x, T y, const T o[8], T eps, Partials<T>& r)
+{
+    T cx = lane6_closest_x_(o[0], o[1], o[2], o[3], o[4], o[5], o[6], x, y);
+    T g, dg, ddg;
+    const T c[7] = {o[0], o[1], o[2], o[3], o[4], o[5], o[6]};
+    poly6_(c, cx, g, dg, ddg);
+    T eta = T(1) + dg * ddg + dg * dg - y * ddg;
+    if (abs_(eta) < eps) eta = eps;
+    T ie = div_(T(2), eta);
+    r.h = (cx - x) * (cx - x) + (g - y) * (g - y) - o[7];
+    r.hx = ie * ((x - cx) * (eta - T(1)) - (y - g) * dg);
+    r.hy = ie * (-(x - cx) * dg + (y - g) * (eta - dg * dg));
+    r.hth = T(0);
+    r.hv = T(0);
+    r.ht = T(0);
+}
+
 // Per-agent quantities every row needs.
 template <typename T> struct Ego {
     T x, y, th, v, cth, sth;
@@ -279,6 +341,9 @@ __device__ inline bool slot_partials_(int type, const T o_in[8], const Ego<T>& e
     case SCCBF_OBS_ELLIPSE: ellipse_(e.x, e.y, o, d); return true;
     case SCCBF_OBS_CONE: cone_(e.x, e.y, e.th, e.v, e.cth, e.sth, o, p.zero_tol, d); return true;
     case SCCBF_OBS_LANE: lane_(e.x, e.y, o, p.zero_tol, d); return true;
+#ifndef SCCBF_NO_LANE6
+    case SCCBF_OBS_LANE6: lane6_(e.x, e.y, o, p.zero_tol, d); return true;
+#endif
     case SCCBF_OBS_RADIAL: radial_(e.x, e.y, e.v, o, d); return true;
     case SCCBF_OBS_ELLIPSE_PREP: ellipse_prep_(e.x, e.y, o, d); return true;
     case SCCBF_OBS_CONE_PREP: cone_prep_(e.x, e.y, e.th, e.v, e.cth, e.sth, o, p.zero_tol, d); return true;

@@ -12,6 +12,7 @@ import numpy as np
 
 OBS_ELLIPSE, OBS_CONE, OBS_LANE, OBS_RADIAL, OBS_EMPTY = 0, 1, 2, 3, 255
 OBS_ELLIPSE_PREP, OBS_CONE_PREP = 4, 5
+OBS_LANE6 = 8
 
 MAX_STEER = np.radians(30.0)
 TARGET_SPEED = 30.0 / 3.6
@@ -179,9 +180,11 @@ def radial_seekers(M=32, seed=1234 + 2, A=1):
                 obs_type=np.full(M, OBS_RADIAL, dtype=np.uint8))
 
 
-def lanes_and_cones(A=16384, n_cone=6, seed=1234 + 5, lane_y=(19.4, 10.4), buffer=1.5):
+def lanes_and_cones(A=16384, n_cone=6, seed=1234 + 5, lane_y=(19.4, 10.4), buffer=1.5, curved=False):
     """Two straight lane boundaries (degree-1 PolyLane, default buffer 1.5) plus n_cone
-    vehicle cones; ego between the lanes heading roughly along +x."""
+    vehicle cones; ego between the lanes heading roughly along +x.  curved: the boundaries are gently curved
+    polynomials of degree 5 and 6 instead (kind 8: c0 ... c6, buffer), a few decimetres off the straight ones over
+    the stretch the agents are on."""
     rng = np.random.default_rng(seed)
     state = np.empty((A, 4))
     state[:, 0] = rng.uniform(-95, 0, A)
@@ -196,6 +199,13 @@ def lanes_and_cones(A=16384, n_cone=6, seed=1234 + 5, lane_y=(19.4, 10.4), buffe
     u_ref = np.empty((A, 2))
     u_ref[:, 0] = KP * (TARGET_SPEED - state[:, 3])
     u_ref[:, 1] = rng.uniform(-0.2, 0.2, A)
-    types = np.array([OBS_LANE, OBS_LANE] + [OBS_CONE] * n_cone, dtype=np.uint8)
+    lane_kind = OBS_LANE
+    if curved:
+        lane_kind = OBS_LANE6
+        lanes[..., 4] = 0.0
+        lanes[..., 7] = buffer
+        lanes[0, :, 1:6] = [2e-3, -4e-5, 3e-7, 2e-9, -1e-11]              # degree 5
+        lanes[1, :, 1:7] = [-1e-3, 3e-5, 2e-7, -3e-9, 2e-11, 1e-13]       # degree 6
+    types = np.array([lane_kind, lane_kind] + [OBS_CONE] * n_cone, dtype=np.uint8)
     return dict(state=state, u_ref=u_ref, obs=_pack(np.concatenate([lanes, cones], axis=0)),
                 obs_type=types)

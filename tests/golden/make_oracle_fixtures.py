@@ -6,12 +6,13 @@ make_reference_fixtures.py).  These vectors pin the ORACLE to itself, so that a 
 the answers every GPU parity test is measured against without a test noticing, and they give the HIP path a
 fixed set of inputs that includes the degenerate cases of every obstacle kind:
 
-  barriers  per kind (ellipse, cone, lane, radial): ego state (4), slot (8) -> h, dh/dx, dh/dy, dh/dtheta,
+  barriers  per kind (ellipse, cone, lane, radial, lane of degree up to 6): ego state (4), slot (8) -> h, dh/dx, dh/dy, dh/dtheta,
             dh/dv, dh/dt; random cases plus: the ego at the ellipse's centre; a cone seen from inside its
             radius, from its rim, from its centre, at the ego's own velocity (relative speed zero) and with a
             slip offset; a lane point whose eta (cbf/obstacles.py:633-636) falls below ZERO_TOL; a radial
             obstacle around an ego at rest
-  filters   64 agents x 16 mixed slots and 64 agents x 2 lanes + 6 cones, for every vehicle model (DBM in
+  filters   64 agents x 16 mixed slots, 64 agents x 2 lanes + 6 cones and the same with lane polynomials of degree 5
+            and 6 (kind 8), for every vehicle model (DBM in
             steering and in slip coordinates, KBM, DUM, SADBM with its slip state) -> rows, input, status
   qp        hand-made row sets (duplicates, parallel and nearly parallel rows, infeasible pair, equality,
             0.u >= 1, empty row, vertex-active and empty triangles, badly scaled rows, 16 tangents to a circle)
@@ -81,6 +82,19 @@ def barrier_cases():
         r = rng.uniform(1.5, 2.0)
         add(orc.OBS_RADIAL, s, [s[0] + rg * np.cos(br), s[1] + rg * np.sin(br), r, r, rng.uniform(-4, 4), rng.uniform(-4, 4), 1.0])
     add(orc.OBS_RADIAL, [0.0, 0.0, 0.0, 0.0], [12.0, -3.0, 1.7, 1.7, -3.0, 0.75, 1.0])       # the scenario's ego at rest
+    # lanes of degree 4 ... 6 (a generator of their own, so that the cases above stay what they were): c0 ... c6, buffer
+    rng = np.random.default_rng(20261115)
+    for i in range(36):
+        s = ego()
+        deg = 4 + i % 3
+        c = np.zeros(7)
+        c[1:deg + 1] = [rng.uniform(-0.3, 0.3), rng.uniform(-0.01, 0.01), rng.uniform(-1e-4, 1e-4), rng.uniform(-2e-6, 2e-6),
+                        rng.uniform(-3e-8, 3e-8), rng.uniform(-4e-10, 4e-10)][:deg]
+        c[0] = s[1] + rng.uniform(-6, 6) - np.polynomial.polynomial.polyval(s[0], c)
+        add(orc.OBS_LANE6, s, list(c) + [1.5])
+    add(orc.OBS_LANE6, [5.0, 13.0, 0.1, 8.0], [17.4, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 1.5])     # the shipped straight lane in this form
+    add(orc.OBS_LANE6, [0.485, 10.2, 0.0, 5.0], [5.0, 0.0, 0.05, 0.0, 0.0, 0.0, 0.0, 1.5])   # eta below ZERO_TOL, as above
+    add(orc.OBS_LANE6, [2.0, 3.0, 0.5, 6.0], [1.0, 0.2, -0.03, 0.004, 5e-4, -6e-5, 7e-6, 0.8])   # every coefficient at work
     kinds = np.asarray(kinds, dtype=np.uint8)
     states, slots = np.stack(states), np.stack(slots)
     out = np.stack([[orc.barrier(int(k), s, o)[n] for n in ("h", "hx", "hy", "hth", "hv", "ht")]
@@ -91,7 +105,8 @@ def barrier_cases():
 def filter_cases():
     out = {}
     batches = {"mixed16": scenarios.config4(A=64, nominal="uniform", seed=11),
-               "lanes2_cones6": scenarios.lanes_and_cones(A=64, seed=12)}
+               "lanes2_cones6": scenarios.lanes_and_cones(A=64, seed=12),
+               "lanes6_cones6": scenarios.lanes_and_cones(A=64, seed=13, curved=True)}
     rng = np.random.default_rng(7)
     for name, w in batches.items():
         for key in ("state", "u_ref", "obs", "obs_type"):

@@ -55,8 +55,11 @@ def test_cone_lane_radial_slots():
     lane = PolyLane(np.array([19.4, 0.0]), s=[0, 15, 0, 3])
     assert lane.order == 1 and lane.slot() == (2, [19.4, 0.0, 0.0, 0.0, 1.5, 0.0, 0.0, 0.0])
     assert np.allclose(lane.evaluate_polynomial(np.array([0.0, 2.0])), [19.4, 19.4])
+    quintic = PolyLane(np.array([1.0, 0.2, -0.03, 0.004, 5e-4, -6e-5]), buffer=0.8)       # degree 4 ... 6: the long kind
+    assert quintic.order == 5 and quintic.slot() == (8, [1.0, 0.2, -0.03, 0.004, 5e-4, -6e-5, 0.0, 0.8])
+    assert PolyLane(np.array([3.0, 0.1, 0, 0, 0, 0, 0])).slot()[0] == 2                     # zeros beyond the cubic: kind 2
     with pytest.raises(ValueError):
-        PolyLane(np.array([0, 0, 0, 0, 1.0]))
+        PolyLane(np.array([0, 0, 0, 0, 0, 0, 0, 1.0]))
     r = RadialEllipse2D(1.7, 1.7, center=Vector2(5, 5), kv=1.0)
     r.update_velocity(Vector2(-1, -1))
     assert r.slot() == (3, [5, 5, 1.7, 1.7, -1, -1, 1.0, 0.0])

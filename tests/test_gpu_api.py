@@ -52,12 +52,14 @@ def test_object_api_partials_and_rows(oracle):
     ol[2] = PolyLane(np.array([9.0, 0.05, 0.002, -1e-4]), s=s)
     ol[3] = RadialEllipse2D(1.7, 1.7, center=Vector2(12, 9), kv=1.0)
     ol[3].update_velocity(Vector2(-2.0, -1.0))
+    ol[4] = PolyLane(np.array([-6.0, 0.1, -0.004, 2e-4, 3e-6, -2e-7, 1e-9]), s=s, buffer=1.0)   # degree 6
     ol.update_state(s=s)
     kinds, slots = ol.slots()
-    exp = [oracle.barrier(int(kinds[i]), s, slots[i]) for i in range(4)]
+    assert list(kinds) == [0, 1, 2, 3, 8]
+    exp = [oracle.barrier(int(kinds[i]), s, slots[i]) for i in range(5)]
     for name, key in (("f", "h"), ("dx", "hx"), ("dy", "hy"), ("dtheta", "hth"), ("dv", "hv"), ("dt", "ht")):
         got = getattr(ol, name)()
-        assert got.shape == (4, 1)
+        assert got.shape == (5, 1)
         assert np.allclose(got[:, 0], [e[key] for e in exp], rtol=1e-10, atol=1e-10), name
         for i, o in enumerate(ol.values()):
             assert abs(getattr(o, name)() - exp[i][key]) <= 1e-10 * (1 + abs(exp[i][key]))
@@ -71,7 +73,7 @@ def test_object_api_partials_and_rows(oracle):
     cbf.set_qp_cost_weight(np.diag([0.5, 0.5]))
     info, u = cbf.solve_cbf(np.array([0.5, 0.05]), return_solver=True)
     p = oracle.make_params(alpha=0.8, R=(0.5, 0, 0, 0.5))
-    obs = np.ascontiguousarray(slots.reshape(4, 2, 1, 4))
+    obs = np.ascontiguousarray(slots.reshape(5, 2, 1, 4))
     uo, so, ro = oracle.solve_batch(p, s[None], np.array([[0.5, 0.05]]), obs, kinds, want_rows=True)
     assert info["status_code"] == so[0]
     assert np.allclose(info["rows"], ro[:, 0, :], rtol=1e-9, atol=1e-9)

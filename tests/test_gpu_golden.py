@@ -66,7 +66,7 @@ def _filter(model):
 
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
 @pytest.mark.parametrize("model", ["dbm", "dbm_slip_io", "kbm", "dum", "sadbm"])
-@pytest.mark.parametrize("name", ["mixed16", "lanes2_cones6"])
+@pytest.mark.parametrize("name", ["mixed16", "lanes2_cones6", "lanes6_cones6"])
 def test_filter_of_every_model(name, model, dtype):
     state, obs, ty = G[name + "_state"], G[name + "_obs"], G[name + "_obs_type"]
     u_ref = G[name + "_u_ref_dum"] if model == "dum" else G[name + "_u_ref"]

@@ -16,9 +16,10 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
 @pytest.mark.parametrize("lanes", [0, 4, 8, 16])
-@pytest.mark.parametrize("name", ["mixed16", "lanes2_cones6"])
+@pytest.mark.parametrize("name", ["mixed16", "lanes2_cones6", "lanes6_cones6"])
 def test_dum_matches_oracle(oracle, name, dtype, lanes):
-    w = scenarios.config4(A=4096, nominal="uniform") if name == "mixed16" else scenarios.lanes_and_cones(A=4096)
+    w = (scenarios.config4(A=4096, nominal="uniform") if name == "mixed16"
+         else scenarios.lanes_and_cones(A=4096, curved=(name == "lanes6_cones6")))
     w["u_ref"][:, 1] *= 3.0     # yaw rates, not steering angles
     p = oracle.make_params(alpha=1.0, R=R_HALF.reshape(-1), dynamics=oracle.DYN_DUM)
     uo, so, ro = oracle.solve_batch(p, w["state"], w["u_ref"], w["obs"], w["obs_type"], want_rows=True)

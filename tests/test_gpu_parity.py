@@ -108,6 +108,8 @@ SCENARIOS = {
     "ellipse8": lambda: scenarios.config3(A=4096),
     "lanes2_cones6": lambda: scenarios.lanes_and_cones(A=4096),
     "radial32": lambda: scenarios.radial_seekers(M=32, A=257, seed=5),
+    # lane polynomials of degree 5 and 6 (kind 8: seven coefficients and the buffer)
+    "lanes6_cones6": lambda: scenarios.lanes_and_cones(A=4096, curved=True),
     # the same obstacles with their per-obstacle constants evaluated into the slot (kinds 4, 5)
     "mixed16_prepared": lambda: scenarios.prepared(scenarios.config4(A=4096, nominal="uniform")),
     "lanes2_cones6_prepared": lambda: scenarios.prepared(scenarios.lanes_and_cones(A=4096)),

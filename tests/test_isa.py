@@ -18,6 +18,7 @@ HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 KERNELS = """
 #include "sccbf_loop.hip.h"
+#include "sccbf_batches.hip.h"
 namespace {
 #define GROUP(T, G, RPL, NT) template __global__ void k_group<T, G, RPL, false, NT>( \\
     long long, const T*, const T*, const T*, const unsigned char*, int, unsigned, const KArgs<T>);
@@ -26,6 +27,9 @@ GROUP(float, 4, 4, true)
 GROUP(float, 1, 16, false)
 GROUP(float, 16, 1, false)
 GROUP(double, 4, 4, false)
+GROUP(double, 4, 4, true)
+template __global__ void k_group_batches<float, 4, 4, true>(const sccbf_batch*, int, unsigned, const KArgs<float>);
+template __global__ void k_group_batches<double, 4, 4, true>(const sccbf_batch*, int, unsigned, const KArgs<double>);
 template __global__ void k_nominal<float>(const NArgs<float>);
 }
 """
@@ -99,3 +103,22 @@ def test_fp64_rollout_fits_two_waves_without_scratch(tmp_path):
     _, meta = _kernel(out.read_text(), "_ZN12_GLOBAL__N_19k_rolloutIdLi4ELb0ELi4EEE")
     assert _meta(meta, "private_segment_fixed_size") <= 32
     assert _meta(meta, "next_free_vgpr") <= 256
+
+
+def test_batches_kernels_keep_the_occupancy_of_the_single_launch_kernels(asm):
+    # the kernel of the bench's timed region (twenty batches per launch): as k_group<float, 4, 4>, seven wavefronts per
+    # SIMD, no scratch, counted waits (a loop over several turns per workgroup cost 35 registers and was dropped)
+    body, meta = _kernel(asm, "_ZN12_GLOBAL__N_115k_group_batchesIfLi4ELi4ELb1EEE")
+    waits = [int(n) for n in re.findall(r"s_waitcnt vmcnt\((\d+)\)", body)]
+    assert max(waits) >= 12 and len(set(waits)) >= 12, sorted(set(waits))
+    assert _meta(meta, "private_segment_fixed_size") == 0 and _meta(meta, "next_free_vgpr") <= 72
+
+
+def test_fp64_kernels_fit_four_waves_without_scratch(asm):
+    # fp64 with four rows per lane: 128 registers = four wavefronts per SIMD (a 65536-agent launch is exactly four per
+    # SIMD); the device library's sincos / tan / sqrt / division used to put it at 130
+    for name in ("_ZN12_GLOBAL__N_17k_groupIdLi4ELi4ELb0ELb0EEEv", "_ZN12_GLOBAL__N_17k_groupIdLi4ELi4ELb0ELb1EEEv",
+                 "_ZN12_GLOBAL__N_115k_group_batchesIdLi4ELi4ELb1EEE"):
+        _, meta = _kernel(asm, name)
+        assert _meta(meta, "private_segment_fixed_size") == 0, name
+        assert _meta(meta, "next_free_vgpr") <= 128, name

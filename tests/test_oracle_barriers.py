@@ -151,6 +151,53 @@ def test_lane_closest_point_cubics_vs_scipy_newton_cg(oracle):
     assert checked > 100
 
 
+def test_lane_of_degree_up_to_six(oracle):
+    """PolyLane takes a coefficient array of any length (cbf/obstacles.py:578-593, numpy Polynomial and its
+    derivatives): kind 8 holds seven coefficients.  The closest point is a local minimum of the distance and scipy's
+    Newton-CG from x0 = px (the reference's call with the true Hessian) finds the same one where there is only one;
+    the row is the reference's formula on numpy's Polynomial; a cubic gives what the cubic kind gives."""
+    rng = np.random.default_rng(41)
+    checked = 0
+    for i in range(200):
+        deg = 4 + i % 3
+        c = np.zeros(7)
+        c[:deg + 1] = [rng.uniform(-5, 5), rng.uniform(-0.5, 0.5), rng.uniform(-0.02, 0.02), rng.uniform(-5e-4, 5e-4),
+                       rng.uniform(-1e-5, 1e-5), rng.uniform(-2e-7, 2e-7), rng.uniform(-3e-9, 3e-9)][:deg + 1]
+        px, py = rng.uniform(-20, 20), rng.uniform(-20, 20)
+        P = np.polynomial.Polynomial(c)
+        x = oracle.lane_closest_x(c, px, py)
+        d1 = 2 * (x - px) + 2 * (P(x) - py) * P.deriv()(x)
+        d2 = 2 * (1 + P.deriv()(x) ** 2 + (P(x) - py) * P.deriv(2)(x))
+        assert abs(d1) <= 1e-6 * (1 + abs(d2)) and d2 > 0                      # a local minimum of the distance
+        s = [px, py, 0.3, 4.0]
+        buf = 0.9
+        d = oracle.barrier(oracle.OBS_LANE6, s, list(c) + [buf])
+        g, dg, ddg = P(x), P.deriv()(x), P.deriv(2)(x)
+        eta = 1 + dg * ddg + dg ** 2 - py * ddg
+        if abs(eta) < EPS:
+            eta = EPS
+        assert abs(d["h"] - ((x - px) ** 2 + (g - py) ** 2 - buf)) < 1e-9
+        assert abs(d["hx"] - (2 / eta) * ((px - x) * (eta - 1) - (py - g) * dg)) < 1e-8 * (1 + abs(d["hx"]))
+        assert abs(d["hy"] - (2 / eta) * (-(px - x) * dg + (py - g) * (eta - dg ** 2))) < 1e-8 * (1 + abs(d["hy"]))
+        assert d["hth"] == 0 and d["hv"] == 0 and d["ht"] == 0
+        mins = _stationary_minima(c, px, py)
+        if len(mins) == 1:
+            dist = lambda z: (z[0] - px) ** 2 + (P(z[0]) - py) ** 2                                   # noqa: E731
+            jac = lambda z: np.array([2 * (z[0] - px) + 2 * (P(z[0]) - py) * P.deriv()(z[0])])        # noqa: E731
+            hes = lambda z: np.array([[2 * (1 + P.deriv()(z[0]) ** 2 + (P(z[0]) - py) * P.deriv(2)(z[0]))]])   # noqa: E731
+            res = minimize(dist, np.array([px]), method="Newton-CG", jac=jac, hess=hes, options={"xtol": 1e-8})
+            assert abs(res.x[0] - x) < 1e-5 * (1 + abs(x))
+            checked += 1
+    assert checked > 60
+    for _ in range(30):      # a cubic through both kinds
+        c = [rng.uniform(-5, 5), rng.uniform(-1, 1), rng.uniform(-0.05, 0.05), rng.uniform(-0.002, 0.002)]
+        s = [rng.uniform(-20, 20), rng.uniform(-20, 20), 0.1, 3.0]
+        a = oracle.barrier(oracle.OBS_LANE, s, c + [1.5, 0, 0, 0])
+        b = oracle.barrier(oracle.OBS_LANE6, s, c + [0, 0, 0, 1.5])
+        for k in ("h", "hx", "hy"):
+            assert abs(a[k] - b[k]) <= 1e-12 * (1 + abs(a[k])), k
+
+
 def test_lane_row_matches_inline_statement(oracle):
     """CBF_lane, stanley_controller_ellipse.py:440-446, with xc from the oracle."""
     rng = np.random.default_rng(5)
