@@ -94,7 +94,8 @@ extern "C" {
 
 /* per-agent result */
 #define SCCBF_STATUS_OPTIMAL 0
-#define SCCBF_STATUS_INFEASIBLE 1 /* rows admit no u; u_out = u_ref (pass-through) */
+#define SCCBF_STATUS_INFEASIBLE 1 /* rows admit no u; u_out = u_ref (pass-through), or the least-violation
+                                     input with SCCBF_FLAG_INFEASIBLE_MIN_VIOLATION */
 #define SCCBF_STATUS_NONFINITE 2  /* NaN/Inf in the inputs; u_out = u_ref */
 
 /* flags */
@@ -116,6 +117,19 @@ extern "C" {
                                           tick brings new ones): they are loaded with the non-temporal
                                           hint and leave the caches to the other arrays.  Without it the
                                           library decides by size.  A hint: results do not depend on it */
+
+#define SCCBF_FLAG_INFEASIBLE_MIN_VIOLATION 64u /* sccbf_solve_* (with rows_out) and sccbf_qp_* only: an agent whose rows
+                                          admit no input keeps status SCCBF_STATUS_INFEASIBLE, but u_out holds, instead of
+                                          the nominal input, the input whose largest row violation is least, the
+                                          violation of row i being (b_i - a_i . u) / sqrt(a_i R^-1 a_i^T), its distance
+                                          to the half-plane in the metric of the cost; among such inputs the one
+                                          nearest to the nominal input in that metric.  Rows with a zero normal and a
+                                          positive right-hand side, which no input satisfies, are left out.  A
+                                          second kernel after the filter, one thread per such agent, reading the
+                                          rows from rows_out (sccbf_solve_*: must not be NULL) or rows (sccbf_qp_*).
+                                          The reference's behaviour here is undefined: it applies whatever cvxopt
+                                          returns for an infeasible program (cbf/cbf.py:213-220).  An agent for which
+                                          the search does not end (48 certificates) keeps the nominal input */
 
 /* error codes */
 #define SCCBF_OK 0

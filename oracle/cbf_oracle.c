@@ -524,6 +524,93 @@ int orc_qp2_incremental(int M, const double* rows, const double R[4], const doub
     return 0;
 }
 
+/* Rows that admit no input: the reference hands cvxopt an infeasible program and applies whatever comes back
+ * (cbf/cbf.py:213-220, the status is never read).  Defined here as the safest input there is: the one whose largest
+ * row violation, measured as the distance to the row's half-plane in the metric of the cost (unit normals in w), is
+ * least; among those the one nearest to the nominal input.  Exact, by enumeration: the least worst-case violation t*
+ * of the linear program  min t  s.t.  at_i . w + t >= bt_i  is the largest value any dual vertex gives, and a dual
+ * vertex is an antiparallel pair (t = (bt_i + bt_j) / 2) or a triple whose normals span the plane positively
+ * (t = sum D_i bt_i / sum D_i with D the cross products of the other two normals); then the QP on the rows relaxed by
+ * t*.  Rows with a zero normal cannot be helped by any input and are left out.  returns 0, t_out = t* (<= 0: the
+ * rows were feasible and the ordinary optimum is returned). */
+int orc_qp2_min_violation(int M, const double* rows, const double R[4], const double u_nom[2],
+                          double u[2], double* t_out, double* work /* 6*M doubles */)
+{
+    double l00, l10, l11;
+    u[0] = u_nom[0];
+    u[1] = u_nom[1];
+    *t_out = 0.0;
+    if (!orc_chol2(R, &l00, &l10, &l11)) return 1;
+    double *at0 = work, *at1 = work + M, *bt = work + 2 * M, *relaxed = work + 3 * M;
+    orc_to_wspace(M, rows, u_nom, l00, l10, l11, at0, at1, bt);
+    double tstar = -INFINITY;
+    for (int i = 0; i < M; ++i) {
+        if (at0[i] == 0.0 && at1[i] == 0.0) continue;
+        for (int j = i + 1; j < M; ++j) {
+            if (at0[j] == 0.0 && at1[j] == 0.0) continue;
+            double cij = at0[i] * at1[j] - at1[i] * at0[j];
+            double dij = at0[i] * at0[j] + at1[i] * at1[j];
+            if (fabs(cij) <= 1e-14 && dij < 0.0) {
+                double t = 0.5 * (bt[i] + bt[j]);
+                if (t > tstar) tstar = t;
+            }
+            for (int k = j + 1; k < M; ++k) {
+                if (at0[k] == 0.0 && at1[k] == 0.0) continue;
+                double d1 = at0[j] * at1[k] - at1[j] * at0[k];
+                double d2 = at0[k] * at1[i] - at1[k] * at0[i];
+                double d3 = cij;
+                if (!((d1 > 1e-14 && d2 > 1e-14 && d3 > 1e-14) || (d1 < -1e-14 && d2 < -1e-14 && d3 < -1e-14))) continue;
+                double t = (d1 * bt[i] + d2 * bt[j] + d3 * bt[k]) / (d1 + d2 + d3);
+                if (t > tstar) tstar = t;
+            }
+        }
+    }
+    *t_out = tstar;
+    double relax = tstar > 0.0 ? tstar * (1.0 + 1e-12) : 0.0;
+    int n = 0;
+    for (int i = 0; i < M; ++i) {
+        double a0 = rows[3 * i], a1 = rows[3 * i + 1], b = rows[3 * i + 2];
+        if (at0[i] == 0.0 && at1[i] == 0.0) continue;   /* left out */
+        double t0 = a0 / l00, t1 = (a1 - l10 * t0) / l11;
+        double nrm = sqrt(t0 * t0 + t1 * t1);
+        relaxed[3 * n] = a0;
+        relaxed[3 * n + 1] = a1;
+        relaxed[3 * n + 2] = b - relax * nrm;
+        ++n;
+    }
+    return orc_qp2_enum(n, relaxed, R, u_nom, u, work);   /* work[0 .. 3n) is free again: its rows sit behind it */
+}
+
+int orc_qp_batch(const orc_params* p, int64_t A, int32_t M, const double* rows_in, const double* u_nom_in,
+                 double* u_out, int32_t* status, int use_incremental);
+
+/* orc_qp_batch with the least-violation answer for the agents whose rows admit no input: u_out holds it, status
+ * stays 1, t_out[a] = the least worst-case violation (0 for the others). */
+int orc_qp_min_violation_batch(const orc_params* p, int64_t A, int32_t M, const double* rows_in,
+                               const double* u_nom_in, double* u_out, int32_t* status, double* t_out)
+{
+    if (!p || A < 0 || M < 0 || M > 64) return -1;   /* enumeration over triples: small M only */
+    int rc = orc_qp_batch(p, A, M, rows_in, u_nom_in, u_out, status, 0);
+    if (rc != 0) return rc;
+#pragma omp parallel for schedule(static)
+    for (int64_t a = 0; a < A; ++a) {
+        t_out[a] = 0.0;
+        if (status[a] != 1) continue;
+        double rows[3 * 64], work[6 * 64];
+        for (int m = 0; m < M; ++m) {
+            const double* ri = rows_in + ((size_t)m * A + a) * 4;
+            rows[3 * m] = ri[0]; rows[3 * m + 1] = ri[1]; rows[3 * m + 2] = ri[2];
+        }
+        double u_nom[2] = {u_nom_in[2 * a], u_nom_in[2 * a + 1]}, u[2], t;
+        if (orc_qp2_min_violation(M, rows, p->R, u_nom, u, &t, work) == 0) {
+            u_out[2 * a] = u[0];
+            u_out[2 * a + 1] = u[1];
+            t_out[a] = t > 0.0 ? t : 0.0;   /* only rows that no input satisfies stood in the way: nothing left to violate */
+        }
+    }
+    return 0;
+}
+
 /* ------------------------------------------------------------ whole tick, batched */
 
 static int orc_finite(double x) { return isfinite(x); }

@@ -172,6 +172,27 @@ def qp_batch(params, rows, u_nom, incremental=False):
     return u_out, status
 
 
+def qp_min_violation_batch(params, rows, u_nom):
+    """QP stage with the least-violation answer where the rows admit no input: rows (M,A,4), u_nom (A,2) ->
+    u (A,2), status (A,) (1 stays 1), t (A,) = the least worst-case violation of those agents (distance to the
+    row's half-plane in the metric of the cost), 0 for the others.  Enumeration over row triples: M <= 64."""
+    rows, u_nom = _f64(rows), _f64(u_nom)
+    M, A = rows.shape[0], rows.shape[1]
+    assert rows.shape == (M, A, 4) and u_nom.shape == (A, 2)
+    u_out, t = np.empty((A, 2)), np.empty(A)
+    status = np.empty(A, dtype=np.int32)
+    L = lib()
+    L.orc_qp_min_violation_batch.restype = C.c_int
+    L.orc_qp_min_violation_batch.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.POINTER(C.c_double),
+                                             C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32),
+                                             C.POINTER(C.c_double)]
+    rc = L.orc_qp_min_violation_batch(C.byref(params), A, M, _dp(rows), _dp(u_nom), _dp(u_out),
+                                      status.ctypes.data_as(C.POINTER(C.c_int32)), _dp(t))
+    if rc != 0:
+        raise ValueError("orc_qp_min_violation_batch failed: %d" % rc)
+    return u_out, status, t
+
+
 def barrier(kind, s, o, zero_tol=1e-3):
     """h and partials of one obstacle slot: returns dict h,hx,hy,hth,hv,ht."""
     s, o8 = _f64(s), np.zeros(8)

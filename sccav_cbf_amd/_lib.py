@@ -19,6 +19,7 @@ STATUS_OPTIMAL, STATUS_INFEASIBLE, STATUS_NONFINITE = 0, 1, 2
 FLAG_OBS_SHARED, FLAG_TYPE_PER_AGENT, FLAG_SLIP_IO, FLAG_OBS_TILED = 1, 2, 4, 8
 FLAG_CONE_BETA_STATE = 16
 FLAG_OBS_STREAMED = 32
+FLAG_INFEASIBLE_MIN_VIOLATION = 64
 MAX_ROWS = 1024
 ERR_ARG, ERR_ROWS, ERR_WEIGHT, ERR_LAUNCH, ERR_VARIANT, ERR_NO_DEVICE = -1, -2, -3, -4, -5, -6
 ERR_BATCHES = -7

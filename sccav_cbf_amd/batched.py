@@ -36,7 +36,7 @@ class BatchedCBF:
     """
 
     def __init__(self, alpha=1.0, lr=1.45, lf=1.45, L=2.9, R=None, dynamics="dbm",
-                 zero_tol=1e-3, lanes_per_qp=0, slip_io=False, streamed_obs=False):
+                 zero_tol=1e-3, lanes_per_qp=0, slip_io=False, streamed_obs=False, min_violation=False):
         self._lib = _lib.load()
         self.params = _lib.Params()
         self._lib.sccbf_default_params(C.byref(self.params))
@@ -49,6 +49,10 @@ class BatchedCBF:
         self.slip_io = bool(slip_io)
         # streamed_obs: every call brings obstacle slots that are not read again soon (a performance hint)
         self.streamed_obs = bool(streamed_obs)
+        # min_violation: an agent whose rows admit no input (status 1) gets, instead of its nominal input, the input
+        # whose largest row violation is least (SCCBF_FLAG_INFEASIBLE_MIN_VIOLATION): solve() of the bicycle and unicycle
+        # models and solve_qp(); solve() then always returns the rows as well (the second pass reads them)
+        self.min_violation = bool(min_violation)
         self.set_qp_cost_weight(np.eye(2) if R is None else R)
 
     # -- setters with the reference's names (cbf/cbf.py:147-157)
@@ -124,6 +128,11 @@ class BatchedCBF:
             u_out = torch.empty((A, 2), dtype=dt, device=dev)
         if status is None:
             status = torch.empty((A,), dtype=torch.int32, device=dev)
+        if self.min_violation:
+            if sadbm or step_dt is not None:
+                raise ValueError("min_violation goes with the plain solve of the bicycle and unicycle models")
+            flags |= _lib.FLAG_INFEASIBLE_MIN_VIOLATION
+            want_rows = True
         if want_rows and rows_out is None:
             rows_out = torch.empty((M, A, 4), dtype=dt, device=dev)
         for name, t, shape, dtype in (("u_out", u_out, (A, 2), dt), ("status", status, (A,), torch.int32),
@@ -235,6 +244,7 @@ class BatchedCBF:
         if status is None:
             status = torch.empty((A,), dtype=torch.int32, device=dev)
         fn = self._lib.sccbf_qp_f32 if dt == torch.float32 else self._lib.sccbf_qp_f64
+        self.params.flags = _lib.FLAG_INFEASIBLE_MIN_VIOLATION if self.min_violation else 0
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
             rc = fn(C.byref(self.params), A, M, _ptr(rows), _ptr(u_nom), _ptr(u_out), _ptr(status),

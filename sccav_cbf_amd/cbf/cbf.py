@@ -34,7 +34,10 @@ def _note_status(flt, status):
     """Keep the device's verdict on the filter object and say so when the answer is the unfiltered
     nominal input (the reference never looks at cvxopt's status, cbf/cbf.py:213-220)."""
     flt.last_status = int(status)
-    if status != 0:
+    if status == 1 and getattr(flt, "infeasible_policy", "nominal") == "min_violation":
+        warnings.warn("CBF-QP infeasible: no input satisfies every row; solve_cbf returns the input whose largest row "
+                      "violation is least (last_status = 1)", CBFStatusWarning, stacklevel=3)
+    elif status != 0:
         warnings.warn("CBF-QP %s: solve_cbf returns the nominal input unchanged (last_status = %d)"
                       % (_STATUS.get(status, "unknown"), status), CBFStatusWarning, stacklevel=3)
 
@@ -54,6 +57,10 @@ class _FilterBase:
         self._L = 2.9
         self.s = np.zeros(4)
         self.last_status = 0   # 0 optimal, 1 infeasible, 2 non-finite input: of the latest solve_cbf
+        # what solve_cbf returns when no input satisfies every row (the reference applies whatever cvxopt hands back,
+        # cbf/cbf.py:213-220): "nominal" = u_ref unchanged, "min_violation" = the input whose largest row violation
+        # (distance to the row's half-plane in the metric of R) is least; DBM, KBM and DUM filters
+        self.infeasible_policy = "nominal"
 
     def set_alpha(self, alpha=1.0):
         self._alpha = alpha
@@ -82,7 +89,10 @@ class _FilterBase:
                              "list so that it is non-empty in order to move forward.")
         u_ref = np.asarray(u_ref, dtype=np.float64).reshape(-1)
         kinds, slots = self.obstacle_list2d.slots()
-        u, status, rows = _device.solve(self._params(), self.s, u_ref, kinds, slots)
+        if self.infeasible_policy not in ("nominal", "min_violation"):
+            raise ValueError("infeasible_policy: 'nominal' or 'min_violation'")
+        flags = _lib.FLAG_INFEASIBLE_MIN_VIOLATION if self.infeasible_policy == "min_violation" else 0
+        u, status, rows = _device.solve(self._params(flags), self.s, u_ref, kinds, slots)
         _note_status(self, status)
         info = {"x": u.copy(), "status": _STATUS.get(status, "unknown"), "status_code": status,
                 "rows": rows}
@@ -180,6 +190,9 @@ class SADBM_CBF_2DS(DBM_CBF_2DS):
             self.beta_ref_last = beta_ref
             raise ValueError("Cannot solve CBF for an empty obstacle list. Update the obstacle "
                              "list so that it is non-empty in order to move forward.")
+        if self.infeasible_policy != "nominal":
+            raise ValueError("the steer-rate model has advanced its slip state with the nominal input by the time the rows "
+                             "turn out to admit none: infeasible_policy 'nominal' only")
         kinds, slots = self.obstacle_list2d.slots()
         last = self.beta_ref_last
         u, status, rows, slip = _device.solve_sa(self._params(), self._dt, self.s, [self._beta, last], u_ref,

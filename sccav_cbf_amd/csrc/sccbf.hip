@@ -35,6 +35,7 @@
 #include "sccbf_ext.hip.h"
 #include "sccbf_ingest.hip.h"
 #include "sccbf_batches.hip.h"
+#include "sccbf_minviol.hip.h"
 
 // The library is built from this one source in three parts that compile side by side (_build.py):
 // the fp32 entry points, the fp64 ones, and sccbf_rollout_f64 on its own, because that part is compiled
@@ -333,6 +334,18 @@ int dispatch_ext(const sccbf_params* sp, const KArgs<T>& k, const XArgs<T>& x, v
     return SCCBF_ERR_VARIANT;
 }
 
+// SCCBF_FLAG_INFEASIBLE_MIN_VIOLATION: second pass over the agents the filter has just reported infeasible
+// transform: 0 the model's output map (DBM / KBM steering), 1 none (DUM, slip coordinates), 2 none and no state (QP stage)
+template <typename T>
+int launch_min_violation(const KArgs<T>& k, const T* rows, int transform, void* stream)
+{
+    const long long blocks = (k.A + kBlock - 1) / kBlock;
+    if (blocks > 0x7fffffffLL) return SCCBF_ERR_ARG;
+    launch_((k_min_violation<T>), dim3((unsigned)blocks), dim3(kBlock), 0, reinterpret_cast<hipStream_t>(stream), k, rows,
+            transform);
+    return launched_();
+}
+
 // sccbf_prewarm: the attribute that lets a workgroup take more than 64 KB of LDS, for every kernel of this part of the
 // library that may ask for it (the kernels that keep the rows in LDS only), on the current device
 template <typename T, int G> bool prewarm_wave_()
@@ -365,13 +378,18 @@ int solve_impl(const sccbf_params* sp, int64_t A, int32_t M, const T* state, con
     if (A > 0 && M > 0 && (!obs || !obs_type)) return SCCBF_ERR_ARG;
     k.state = state; k.u_ref = u_ref; k.obs = obs; k.obs_type = obs_type;
     k.u_out = u_out; k.status = status; k.rows_out = rows_out;
+    const bool min_viol = (sp->flags & SCCBF_FLAG_INFEASIBLE_MIN_VIOLATION) && A > 0 && M > 0;
+    if (min_viol && !rows_out) return SCCBF_ERR_ARG;  // the second pass works on the rows the filter writes
     if (sp->dynamics == SCCBF_DYN_DUM && A > 0 && M > 0) {
         if (sp->flags & SCCBF_FLAG_CONE_BETA_STATE) return SCCBF_ERR_ARG;
         XArgs<T> x;
         x.slip = nullptr; x.dt = T(0); x.inv_dt = T(0);
-        return dispatch_ext<T>(sp, k, x, stream);
+        rc = dispatch_ext<T>(sp, k, x, stream);
+        return (rc == SCCBF_OK && min_viol) ? launch_min_violation<T>(k, rows_out, 1, stream) : rc;
     }
-    return dispatch<T, false>(sp, k, stream);
+    rc = dispatch<T, false>(sp, k, stream);
+    if (rc != SCCBF_OK || !min_viol) return rc;
+    return launch_min_violation<T>(k, rows_out, (sp->flags & SCCBF_FLAG_SLIP_IO) ? 1 : 0, stream);
 }
 
 template <typename T>
@@ -388,6 +406,7 @@ int solve_step_impl(const sccbf_params* sp, double max_steer, double dt, int64_t
     int rc = fill_args<T>(sp, A, M, k);
     if (rc != SCCBF_OK) return rc;
     if (sp->dynamics != SCCBF_DYN_DBM || (sp->flags & SCCBF_FLAG_SLIP_IO)) return SCCBF_ERR_ARG;  // the step takes (a, delta)
+    if (sp->flags & SCCBF_FLAG_INFEASIBLE_MIN_VIOLATION) return SCCBF_ERR_ARG;  // a second pass: sccbf_solve_* only
     if (!(max_steer >= 0.0) || !std::isfinite(dt)) return SCCBF_ERR_ARG;
     if (A == 0) return SCCBF_OK;
     if (!state || !u_ref || !u_out || !status) return SCCBF_ERR_ARG;
@@ -415,6 +434,7 @@ int solve_sa_impl(const sccbf_params* sp, double dt, int64_t A, int32_t M, const
     int rc = fill_args<T>(&q, A, M, k);
     if (rc != SCCBF_OK) return rc;
     if (M < 1 || !(dt > 0.0) || !std::isfinite(dt) || (q.flags & SCCBF_FLAG_SLIP_IO)) return SCCBF_ERR_ARG;
+    if (q.flags & SCCBF_FLAG_INFEASIBLE_MIN_VIOLATION) return SCCBF_ERR_ARG;  // the slip state has been advanced already
     if (A == 0) return SCCBF_OK;
     if (!state || !slip || !u_ref || !u_out || !status || !obs || !obs_type) return SCCBF_ERR_ARG;
     k.state = state; k.u_ref = u_ref; k.obs = obs; k.obs_type = obs_type;
@@ -453,6 +473,7 @@ int qp_impl(const sccbf_params* sp, int64_t A, int32_t M, const T* rows, const T
     q.dynamics = SCCBF_DYN_DBM;  // unused by the QP stage; keep validation independent of it
     if (!(q.lr > 0.0)) q.lr = 1.0;
     if (!(q.lf + q.lr > 0.0)) q.lf = 1.0;
+    const bool min_viol = (q.flags & SCCBF_FLAG_INFEASIBLE_MIN_VIOLATION) && A > 0 && M > 0;
     q.flags = 0;
     int rc = fill_args<T>(&q, A, M, k);
     if (rc != SCCBF_OK) return rc;
@@ -460,7 +481,8 @@ int qp_impl(const sccbf_params* sp, int64_t A, int32_t M, const T* rows, const T
     if (A > 0 && M > 0 && !rows) return SCCBF_ERR_ARG;
     k.state = nullptr; k.u_ref = u_nom; k.obs = rows; k.obs_type = nullptr;
     k.u_out = u_out; k.status = status; k.rows_out = nullptr;
-    return dispatch<T, true>(&q, k, stream);
+    rc = dispatch<T, true>(&q, k, stream);
+    return (rc == SCCBF_OK && min_viol) ? launch_min_violation<T>(k, rows, 2, stream) : rc;
 }
 
 template <typename T>
@@ -533,7 +555,8 @@ int rollout_impl(const sccbf_params* sp, const sccbf_nominal_params* np, const s
         rp->motion != SCCBF_MOTION_SEEKER)
         return SCCBF_ERR_ARG;
     if (rp->motion == SCCBF_MOTION_SEEKER && !(rp->seek_gain >= 0.0 && rp->seek_v_min >= 0.0)) return SCCBF_ERR_ARG;
-    if (sp->flags & (SCCBF_FLAG_SLIP_IO | SCCBF_FLAG_CONE_BETA_STATE)) return SCCBF_ERR_ARG;  // works in the caller's coordinates
+    if (sp->flags & (SCCBF_FLAG_SLIP_IO | SCCBF_FLAG_CONE_BETA_STATE | SCCBF_FLAG_INFEASIBLE_MIN_VIOLATION))
+        return SCCBF_ERR_ARG;  // works in the caller's coordinates; no second pass inside the tick loop
     if (sp->flags & SCCBF_FLAG_OBS_SHARED) return SCCBF_ERR_ARG;  // moving obstacles are per agent
     const bool sadbm = sp->dynamics == SCCBF_DYN_SADBM;
     if ((sp->dynamics == SCCBF_DYN_KBM || sp->dynamics == SCCBF_DYN_DUM) && !(sp->L > 0.0)) return SCCBF_ERR_ARG;
@@ -721,7 +744,7 @@ int batches_launch(const sccbf_params* sp, int32_t K, int32_t M, int64_t a_max, 
     if (rc != SCCBF_OK) return rc;
     // the models of sccbf_solve_* whose kernels take nothing but these arrays; no shared-nothing flags beyond its own
     if (sp->dynamics != SCCBF_DYN_DBM && sp->dynamics != SCCBF_DYN_KBM) return SCCBF_ERR_ARG;
-    if (sp->flags & SCCBF_FLAG_CONE_BETA_STATE) return SCCBF_ERR_ARG;
+    if (sp->flags & (SCCBF_FLAG_CONE_BETA_STATE | SCCBF_FLAG_INFEASIBLE_MIN_VIOLATION)) return SCCBF_ERR_ARG;
     if (K == 0 || a_max == 0) return SCCBF_OK;
     if (!table) return SCCBF_ERR_ARG;
     k.state = nullptr; k.u_ref = nullptr; k.obs = nullptr; k.obs_type = nullptr;

@@ -247,3 +247,21 @@ def test_static_batches_argument_validation(lib):
     recs[1].A = 0
     p.dynamics = _lib.DYN_DUM
     assert fn(C.byref(p), 4, 3, 16, recs, None) == -1
+
+
+def test_min_violation_flag_where_it_is_refused(lib):
+    p = _lib.Params()
+    lib.sccbf_default_params(C.byref(p))
+    p.flags = _lib.FLAG_INFEASIBLE_MIN_VIOLATION
+    nul = C.c_void_p(0)
+    one = C.c_void_p(8)    # never dereferenced: every call below returns before a launch
+    assert lib.sccbf_solve_f64(C.byref(p), 4, 2, one, one, one, one, one, one, nul, None) == -1      # needs rows_out
+    assert lib.sccbf_solve_f64(C.byref(p), 0, 2, nul, nul, nul, nul, nul, nul, nul, None) == 0       # nothing to do
+    assert lib.sccbf_solve_step_f32(C.byref(p), 0.5, 0.1, 0, 2, *([nul] * 8)) == -1
+    assert lib.sccbf_solve_sa_f32(C.byref(p), 0.1, 0, 2, *([nul] * 10)) == -1
+    assert lib.sccbf_solve_batches_f32(C.byref(p), 0, 2, 4, nul, None) == -1
+    q, r = _lib.NominalParams(), _lib.RolloutParams()
+    lib.sccbf_default_nominal_params(C.byref(q))
+    lib.sccbf_default_rollout_params(C.byref(r))
+    r.ticks = 1
+    assert lib.sccbf_rollout_f32(C.byref(p), C.byref(q), C.byref(r), 0, 2, 0, *([nul] * 12)) == -1

@@ -211,3 +211,40 @@ def test_object_api_in_a_process_that_never_imported_torch_itself():
     u = cbf.solve_cbf(np.array([0.3, 0.1]))
     assert abs(got[0] - float(u[0])) <= 1e-12 and abs(got[1] - float(u[1])) <= 1e-12
     assert abs(got[0] - 0.3) > 1e-6 or abs(got[1] - 0.1) > 1e-6      # the cone is in the way: the filter acts
+
+
+def test_object_api_least_violation_policy(oracle):
+    """Two circles that leave no admissible input between them: with infeasible_policy = "min_violation" solve_cbf
+    returns the oracle's least-violation input instead of the nominal one; last_status stays 1."""
+    import warnings
+    from sccav_cbf_amd.cbf.cbf import CBFStatusWarning, SADBM_CBF_2DS
+    s = np.array([0.0, 0.0, 0.0, 8.0])
+    cbf = DBM_CBF_2DS(alpha=1.0)
+    cbf.set_model_params(lr=1.45, lf=1.45)
+    cbf.set_qp_cost_weight(np.diag([0.5, 0.5]))
+    cbf.obstacle_list2d.update({0: Ellipse2D(4, 4, Point2(6.0, 2.5)), 1: Ellipse2D(4, 4, Point2(6.0, -2.5)),
+                                2: CollisionCone2D(3.0, s, [9.0, 0.0, np.pi, 4.0])})
+    cbf.update_state(s=s)
+    u_ref = np.array([0.5, 0.02])
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        info, u_nom = cbf.solve_cbf(u_ref, return_solver=True)
+    assert cbf.last_status == 1 and np.array_equal(u_nom, u_ref) and "nominal input unchanged" in str(rec[-1].message)
+    cbf.infeasible_policy = "min_violation"
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        u = cbf.solve_cbf(u_ref)
+    assert cbf.last_status == 1 and issubclass(rec[-1].category, CBFStatusWarning) and "least" in str(rec[-1].message)
+    rows = info["rows"]
+    beta_ref = np.arctan2(1.45 * np.tan(u_ref[1]), 2.9)
+    uo, so, t = oracle.qp_min_violation_batch(oracle.make_params(R=(0.5, 0, 0, 0.5)), rows[:, None, :],
+                                              np.array([[u_ref[0], beta_ref]]))
+    assert so[0] == 1 and t[0] > 0
+    got = np.array([u[0], np.arctan2(1.45 * np.tan(u[1]), 2.9)])
+    assert np.abs(got - uo[0]).max() <= 1e-7 * (1 + np.abs(uo[0]).max())
+    sa = SADBM_CBF_2DS(alpha=1.0, dt=0.1)
+    sa.infeasible_policy = "min_violation"
+    sa.obstacle_list2d.update({0: Ellipse2D(4, 4, Point2(6.0, 2.5))})
+    sa.update_state(s=s)
+    with pytest.raises(ValueError, match="nominal"):
+        sa.solve_cbf(u_ref)

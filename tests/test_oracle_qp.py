@@ -199,3 +199,65 @@ def test_interior_point_at_the_reference_solvers_tolerances_lands_on_the_oracle(
     # measured 7.9e-5: the stopping rule (duality gap 1e-7, or 1e-6 of the cost) leaves the iterate that far from the
     # exact optimum; it is the accuracy to which any number the reference produced was ever defined
     assert worst <= 2e-4, worst
+
+
+def test_least_violation_answer_for_infeasible_rows(oracle):
+    """Rows without a common point: the oracle's answer minimises the largest violation (distance to the row's
+    half-plane in the metric of the cost) and, among such inputs, is the one nearest to the nominal input.  Checked
+    against a linear program for the least worst-case violation (scipy HiGHS) and SLSQP for the nearest point."""
+    from scipy.optimize import linprog
+    rng = np.random.default_rng(77)
+    R = np.array([[2.0, 0.3], [0.3, 1.0]])
+    Lc = np.linalg.cholesky(R)
+    p = oracle.make_params(R=R.reshape(-1))
+    A, M = 400, 6
+    ang = rng.uniform(-np.pi, np.pi, (M, A))
+    rows = np.zeros((M, A, 4))
+    rows[:, :, 0], rows[:, :, 1] = np.cos(ang) * rng.uniform(0.1, 10, (M, A)), np.sin(ang) * rng.uniform(0.1, 10, (M, A))
+    rows[:, :, 2] = rng.normal(3.0, 3.0, (M, A))
+    rows[M - 1, ::7, :3] = (0.0, 0.0, -1.0)            # an empty row among them
+    un = rng.normal(0, 1, (A, 2))
+    u0, st0 = oracle.qp_batch(p, rows, un)
+    u, st, t = oracle.qp_min_violation_batch(p, rows, un)
+    assert np.array_equal(st, st0) and (st == 1).sum() > 150 and (st == 0).sum() > 50
+    assert np.array_equal(u[st == 0], u0[st == 0]) and (t[st == 0] == 0).all()
+    checked = 0
+    for a in np.where(st == 1)[0][:120]:
+        a_u, b_u = rows[:, a, :2], rows[:, a, 2]
+        keep = np.hypot(a_u[:, 0], a_u[:, 1]) > 0
+        at = np.linalg.solve(Lc, a_u[keep].T).T                    # normals in w = Lc^T (u - u_nom)
+        nrm = np.hypot(at[:, 0], at[:, 1])
+        at, bt = at / nrm[:, None], (b_u[keep] - a_u[keep] @ un[a]) / nrm
+        res = linprog(c=[0, 0, 1.0], A_ub=np.c_[-at, -np.ones(len(bt))], b_ub=-bt, bounds=[(None, None)] * 3, method="highs")
+        assert res.status == 0 and abs(res.x[2] - t[a]) <= 1e-8 * (1 + abs(t[a])), (a, res.x[2], t[a])
+        w = Lc.T @ (u[a] - un[a])
+        viol = (bt - at @ w).max()
+        assert abs(viol - t[a]) <= 1e-7 * (1 + abs(t[a]))          # the answer attains the least worst-case violation
+        # and it is the nearest such point to the nominal input: the inputs that attain t* (here to 1e-7) form a set whose
+        # bounding box four linear programs give; generically that set is one point, and the answer lies in it
+        box = []
+        for cvec in ([1, 0], [-1, 0], [0, 1], [0, -1]):
+            rb = linprog(c=cvec, A_ub=-at, b_ub=-(bt - t[a] * (1 + 1e-7) - 1e-9), bounds=[(None, None)] * 2, method="highs")
+            box.append(rb.x if rb.status == 0 else None)
+        if any(b is None for b in box):
+            continue
+        lo = np.array([box[0][0], box[2][1]])
+        hi = np.array([box[1][0], box[3][1]])
+        assert (w >= lo - 1e-6 * (1 + np.abs(w))).all() and (w <= hi + 1e-6 * (1 + np.abs(w))).all(), (a, w, lo, hi)
+        if np.abs(hi - lo).max() > 1e-4 * (1 + np.abs(w).max()):
+            continue                                                # a segment of equally good inputs: not judged here
+        checked += 1
+    assert checked >= 100
+    # hand-made: two rows facing each other with a gap of 1.5 (R = I): the answer is the midline point nearest to u_nom
+    p1 = oracle.make_params(R=(1, 0, 0, 1))
+    r = np.zeros((2, 1, 4))
+    r[0, 0, :3] = (1, 0, 1.0)
+    r[1, 0, :3] = (-1, 0, 0.5)
+    u, st, t = oracle.qp_min_violation_batch(p1, r, np.array([[0.3, 0.7]]))
+    assert st[0] == 1 and abs(t[0] - 0.75) < 1e-12 and np.allclose(u[0], [0.25, 0.7], atol=1e-9)
+    # the empty triangle of the hand-made cases: x >= 1, y >= 2, x + y <= 2.9
+    r = np.zeros((3, 1, 4))
+    r[0, 0, :3], r[1, 0, :3], r[2, 0, :3] = (1, 0, 1.0), (0, 1, 2.0), (-1, -1, -2.9)
+    u, st, t = oracle.qp_min_violation_batch(p1, r, np.array([[0.0, 0.0]]))
+    tt = 0.1 / (2 + np.sqrt(2))                                    # equal distance to the three lines
+    assert st[0] == 1 and abs(t[0] - tt) < 1e-12 and np.allclose(u[0], [1 - tt, 2 - tt], atol=1e-9)
