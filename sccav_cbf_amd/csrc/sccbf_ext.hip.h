@@ -17,7 +17,7 @@ template <typename T> struct XArgs {
 // DUM: reference cbf/cbf.py:237-245, 279-286.   Lg_h = [h_v, h_th],  Lf_h = v (cos(th) h_x + sin(th) h_y)
 // SADBM: reference cbf/cbf.py:338-347, 398-405. Lg_h = [h_v, h_beta],
 //        Lf_h = h_x v cos(th + beta) + h_y v sin(th + beta) + h_th v sin(beta) / lr
-template <typename T>
+template <bool INLINE6 = false, typename T>
 __device__ inline void ext_slot_row_(int type, T (&o)[8], const Ego<T>& e, const KArgs<T>& p, bool sadbm,
                                      bool cone_beta_state, T beta, T cthb, T sthb, T sb,
                                      T& a0, T& a1, T& b, T& h)
@@ -50,7 +50,7 @@ __device__ inline void ext_slot_row_(int type, T (&o)[8], const Ego<T>& e, const
         break;
     case SCCBF_OBS_LANE: lane_(e.x, e.y, o, p.zero_tol, d); break;
 #ifndef SCCBF_NO_LANE6
-    case SCCBF_OBS_LANE6: lane6_(e.x, e.y, o, p.zero_tol, d); break;
+    case SCCBF_OBS_LANE6: lane6_<INLINE6>(e.x, e.y, o, p.zero_tol, d); break;
 #endif
     case SCCBF_OBS_RADIAL: radial_(e.x, e.y, e.v, o, d); break;
     case SCCBF_OBS_ELLIPSE_PREP: ellipse_prep_(e.x, e.y, o, d); break;
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(kBlock) void k_group_ext(const KArgs<T> p, const XA
         T o[8] = {L.oa[r].x, L.oa[r].y, L.oa[r].z, L.oa[r].w, L.ob[r].x, L.ob[r].y, L.ob[r].z, L.ob[r].w};
         const int ty = m < p.M ? L.ty[r] : SCCBF_OBS_EMPTY;
         T a0, a1, b, h;
-        ext_slot_row_(ty, o, q.e, p, q.sadbm, q.cone_beta_state, q.sl.x, q.cthb, q.sthb, q.sb, a0, a1, b, h);
+        ext_slot_row_<(RPL <= 4)>(ty, o, q.e, p, q.sadbm, q.cone_beta_state, q.sl.x, q.cthb, q.sthb, q.sb, a0, a1, b, h);
         if (p.rows_out && m < p.M) reinterpret_cast<v4*>(p.rows_out)[(long long)m * p.A + qp] = v4{a0, a1, b, h};
         chk += a0 * T(0) + a1 * T(0) + b * T(0);
         to_wspace_(a0, a1, b, q.e, p, at0[r], at1[r], bt[r]);
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(kBlock) void k_group_ext(const KArgs<T> p, const XA
 // G lanes per QP, rows staged in LDS only: any M up to SCCBF_MAX_ROWS (k_wave for these models, the same
 // two thread layouts).
 template <typename T, int QPB, int G, bool PAIRED = false>
-__global__ __launch_bounds__(QPB * G) void k_wave_ext(const KArgs<T> p, const XArgs<T> x)
+__global__ __launch_bounds__(QPB * G) __attribute__((amdgpu_waves_per_eu(kWaveWaves<T>))) void k_wave_ext(const KArgs<T> p, const XArgs<T> x)
 {
     using v4 = typename VT<T>::v4;
     using v2 = typename VT<T>::v2;

@@ -83,7 +83,7 @@ __device__ inline int lane_rows_(const KArgs<T>& p, long long qp, int m0, int dm
             const T o[8] = {L.oa[r].x, L.oa[r].y, L.oa[r].z, L.oa[r].w,
                             L.ob[r].x, L.ob[r].y, L.ob[r].z, L.ob[r].w};
             const int ty = m < M ? L.ty[r] : SCCBF_OBS_EMPTY;
-            slot_row_(ty, o, e, p, a0, a1, b, h);
+            slot_row_<(RPL <= 4)>(ty, o, e, p, a0, a1, b, h);
             if (p.rows_out && m < M && live)
                 reinterpret_cast<v4*>(p.rows_out)[(long long)m * p.A + qp] = v4{a0, a1, b, h};
             if (h_min && ty >= 0 && ty <= SCCBF_OBS_LANE6) *h_min = min_(*h_min, h);  // real slots only
@@ -200,7 +200,11 @@ __device__ inline void group_solve_(const KArgs<T>& p, long long qp, int g, cons
 // Wavefronts per SIMD the register allocation of a k_group instantiation is held to (at least): the fp64 kernels with up
 // to four rows per lane sit at 126 ... 130 registers, two either side of the 128 that four wavefronts allow, and the
 // allocator finds the two when asked (nothing spilled: tests/test_isa.py); the others are left alone.
+#ifndef SCCBF_EXP_NO_WAVES_ATTR
 template <typename T, int RPL> constexpr int kGroupWaves = (sizeof(T) == 8 && RPL <= 4) ? 4 : 1;
+#else
+template <typename T, int RPL> constexpr int kGroupWaves = 1;
+#endif
 
 // The arguments every wave needs before it can issue its first loads come first and one
 // by one: the leading 16 dwords of the kernel arguments are preloaded into SGPRs at wave
@@ -409,8 +413,12 @@ __device__ inline void wave_body_(const KArgs<T>& p, unsigned block, unsigned ch
         store_result_(p, qp, QP_ONLY, tab.status[qa], tab.answer[2 * qa], tab.answer[2 * qa + 1], e, ur0, ur1);
 }
 
+// The fp32 kernels of this family sit at 118 ... 130 registers: held to the 128 of four wavefronts per SIMD (two
+// workgroups of eight wavefronts per CU while one forms rows and the other iterates); fp64 is left alone.
+template <typename T> constexpr int kWaveWaves = sizeof(T) == 4 ? 4 : 1;
+
 template <typename T, int QPB, bool QP_ONLY, int G, bool PAIRED = false>
-__global__ __launch_bounds__(QPB * G) void k_wave(const KArgs<T> p)
+__global__ __launch_bounds__(QPB * G) __attribute__((amdgpu_waves_per_eu(kWaveWaves<T>))) void k_wave(const KArgs<T> p)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     wave_body_<T, QPB, QP_ONLY, G, PAIRED>(p, blockIdx.x, smem_raw);

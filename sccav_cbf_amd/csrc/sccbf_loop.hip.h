@@ -561,7 +561,7 @@ void k_rollout(const RArgs<T> a)
                 T o[8] = {L.oa[r].x, L.oa[r].y, L.oa[r].z, L.oa[r].w, L.ob[r].x, L.ob[r].y, L.ob[r].z, L.ob[r].w};
                 const int ty = m < p.M ? L.ty[r] : SCCBF_OBS_EMPTY;
                 T a0, a1, b, h;
-                ext_slot_row_(ty, o, e, p, sadbm, sadbm, sl.x, cthb, sthb, sb, a0, a1, b, h);
+                ext_slot_row_<(RPL <= 4)>(ty, o, e, p, sadbm, sadbm, sl.x, cthb, sthb, sb, a0, a1, b, h);
                 if (ty >= 0 && ty <= SCCBF_OBS_LANE6) hm = min_(hm, h);
                 chk += a0 * T(0) + a1 * T(0) + b * T(0);
                 to_wspace_(a0, a1, b, e, p, at0[r], at1[r], bt[r]);

@@ -216,11 +216,14 @@ template <typename T> __device__ inline void poly6_(const T c[7], T x, T& f, T& 
     ddf = T(2) * c[2] + x * (T(6) * c[3] + x * (T(12) * c[4] + x * (T(20) * c[5] + x * (T(30) * c[6]))));
 }
 
-// Inlined (its loops stay rolled): as a function of its own it needs 24 registers in fp32 and 66 in fp64 below the
-// caller's live ones, which costs the kernels that keep four rows per lane a wavefront per SIMD; inlined it works on
-// the slot's own registers.  The state carried around the loops is kept to x, the step and the distance at x.
+// Two ways to run it.  Inlined (its loops stay rolled), in the kernels that keep up to four rows per lane: as a function of
+// its own it needs 24 registers in fp32 and 66 in fp64 below the caller's live ones, which costs those kernels a wavefront
+// per SIMD, while inlined it works on the slot's own registers.  Called, everywhere else: kernels that unroll sixteen rows
+// per lane would carry sixteen copies of the loop and outgrow the instruction cache (the 128-row launch went from 59 to
+// 306 us), and the kernels that keep the rows in LDS are not bound by registers.  The state carried around the loops is
+// kept to x, the step and the distance at x.
 template <typename T>
-__device__ __forceinline__ T lane6_closest_x_(T c0, T c1, T c2, T c3, T c4, T c5, T c6, T px, T py)
+__device__ __forceinline__ T lane6_closest_x_body_(T c0, T c1, T c2, T c3, T c4, T c5, T c6, T px, T py)
 {
     const T c[7] = {c0, c1, c2, c3, c4, c5, c6};
     T x = px;
@@ -251,9 +254,16 @@ __device__ __forceinline__ T lane6_closest_x_(T c0, T c1, T c2, T c3, T c4, T c5
 }
 
 template <typename T>
+__device__ __noinline__ T lane6_closest_x_call_(T c0, T c1, T c2, T c3, T c4, T c5, T c6, T px, T py)
+{
+    return lane6_closest_x_body_(c0, c1, c2, c3, c4, c5, c6, px, py);
+}
+
+template <bool INLINE6, typename T>
 __device__ inline void lane6_(T x, T y, const T o[8], T eps, Partials<T>& r)
 {
-    T cx = lane6_closest_x_(o[0], o[1], o[2], o[3], o[4], o[5], o[6], x, y);
+    T cx = INLINE6 ? lane6_closest_x_body_(o[0], o[1], o[2], o[3], o[4], o[5], o[6], x, y)
+                   : lane6_closest_x_call_(o[0], o[1], o[2], o[3], o[4], o[5], o[6], x, y);
     T g, dg, ddg;
     const T c[7] = {o[0], o[1], o[2], o[3], o[4], o[5], o[6]};
     poly6_(c, cx, g, dg, ddg);
@@ -324,7 +334,8 @@ __device__ inline void contract_row_(const Partials<T>& d, const Ego<T>& e, cons
 }
 
 // Barrier value and partials of one slot whose kind is known; false for an empty slot.
-template <typename T>
+// INLINE6: the closest-point loop of a degree-6 lane inlined (callers that unroll at most four rows) or called.
+template <bool INLINE6 = false, typename T>
 __device__ inline bool slot_partials_(int type, const T o_in[8], const Ego<T>& e, const KArgs<T>& p, Partials<T>& d)
 {
     T o[8];
@@ -342,7 +353,7 @@ __device__ inline bool slot_partials_(int type, const T o_in[8], const Ego<T>& e
     case SCCBF_OBS_CONE: cone_(e.x, e.y, e.th, e.v, e.cth, e.sth, o, p.zero_tol, d); return true;
     case SCCBF_OBS_LANE: lane_(e.x, e.y, o, p.zero_tol, d); return true;
 #ifndef SCCBF_NO_LANE6
-    case SCCBF_OBS_LANE6: lane6_(e.x, e.y, o, p.zero_tol, d); return true;
+    case SCCBF_OBS_LANE6: lane6_<INLINE6>(e.x, e.y, o, p.zero_tol, d); return true;
 #endif
     case SCCBF_OBS_RADIAL: radial_(e.x, e.y, e.v, o, d); return true;
     case SCCBF_OBS_ELLIPSE_PREP: ellipse_prep_(e.x, e.y, o, d); return true;
@@ -352,12 +363,12 @@ __device__ inline bool slot_partials_(int type, const T o_in[8], const Ego<T>& e
 }
 
 // One obstacle slot -> constraint row  a . u >= b  (u-space) and barrier value h.
-template <typename T>
+template <bool INLINE6 = false, typename T>
 __device__ inline void slot_row_(int type, const T o[8], const Ego<T>& e, const KArgs<T>& p,
                                  T& a0, T& a1, T& b, T& h)
 {
     Partials<T> d;
-    if (!slot_partials_(type, o, e, p, d)) {
+    if (!slot_partials_<INLINE6>(type, o, e, p, d)) {
         a0 = T(0); a1 = T(0); b = T(-1); h = T(1);
         return;
     }

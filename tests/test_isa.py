@@ -28,6 +28,7 @@ GROUP(float, 1, 16, false)
 GROUP(float, 16, 1, false)
 GROUP(double, 4, 4, false)
 GROUP(double, 4, 4, true)
+GROUP(float, 8, 16, true)
 template __global__ void k_group_batches<float, 4, 4, true>(const sccbf_batch*, int, unsigned, const KArgs<float>);
 template __global__ void k_group_batches<double, 4, 4, true>(const sccbf_batch*, int, unsigned, const KArgs<double>);
 template __global__ void k_nominal<float>(const NArgs<float>);
@@ -122,3 +123,14 @@ def test_fp64_kernels_fit_four_waves_without_scratch(asm):
         _, meta = _kernel(asm, name)
         assert _meta(meta, "private_segment_fixed_size") == 0, name
         assert _meta(meta, "next_free_vgpr") <= 128, name
+
+
+def test_sixteen_rows_per_lane_stay_inside_the_instruction_cache(asm):
+    # k_group<float, 8, 16>, the kernel of a 128-row launch, unrolls sixteen rows: everything a row inlines is there sixteen
+    # times.  With the degree-6 closest-point loop inlined it grew past the 64 KB instruction cache and a launch went
+    # from 59 to 306 us; it is a call there (inlined only where at most four rows are unrolled).
+    body, meta = _kernel(asm, "_ZN12_GLOBAL__N_17k_groupIfLi8ELi16ELb0ELb1EEEv")
+    insts = [ln for ln in body.splitlines() if ln.startswith("\t") and ln.strip() and not ln.strip().startswith((".", ";"))]
+    assert len(insts) <= 9800, len(insts)
+    assert "lane6_closest_x_call_" in body
+    assert _meta(meta, "private_segment_fixed_size") == 0
