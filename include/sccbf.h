@@ -27,7 +27,9 @@
  *                           and is broadcast to every agent; with
  *                           SCCBF_FLAG_OBS_TILED it is T[ceil(A/64)][M][2][64][4],
  *                           agent a at tile a/64, position a%64 (the faster
- *                           layout: one contiguous block per 64 agents)
+ *                           layout: one contiguous block per 64 agents); with
+ *                           SCCBF_FLAG_OBS_AGENT_MAJOR it is T[A][M][2][4] (the faster
+ *                           layout for more than 128 slots)
  *   obs_type u8[M]          slot kind, shared by all agents; with
  *                           SCCBF_FLAG_TYPE_PER_AGENT it is u8[M][A]
  *   u_out    T[A][2]        DBM: a*, delta*             KBM: v*, delta*
@@ -108,6 +110,14 @@ extern "C" {
                                         tile one contiguous block of 128 M 4-vectors; the last tile
                                         may be partly unused but must be allocated in full; not
                                         combinable with SCCBF_FLAG_OBS_SHARED */
+#define SCCBF_FLAG_OBS_AGENT_MAJOR 128u /* obs is T[A][M][2][4]: the M slots of an agent side by side (slot m of agent a =
+                                          the 8 scalars from obs + (a M + m) 8 on), the layout of a per-agent obstacle
+                                          list.  The layout for long lists: the kernels for more than 128 rows
+                                          give a workgroup a few agents, whose slots are then one contiguous
+                                          stream (at 257 ... 1024 rows a quarter faster than from tiles or planes,
+                                          where eight agents share every 128-byte line).  Accepted wherever
+                                          SCCBF_FLAG_OBS_TILED is; at most one of SCCBF_FLAG_OBS_SHARED, _TILED and
+                                          _AGENT_MAJOR.  For lists of up to 128 rows tiles are the faster layout */
 #define SCCBF_FLAG_CONE_BETA_STATE 16u /* sccbf_solve_sa_* only: every cone slot takes beta from the
                                           agent's slip state instead of its own o[5], which is what
                                           the reference's cones hold after SADBM's first solve
@@ -505,7 +515,7 @@ int sccbf_rollout_f64(const sccbf_params* p, const sccbf_nominal_params* np,
  *                            extent y) + buffer, theta_o = 0, v_o = speed
  *         SCCBF_OBS_ELLIPSE_PREP, SCCBF_OBS_CONE_PREP   the same two in their prepared forms
  *         anything else      an all-zero slot (pair it with SCCBF_OBS_EMPTY)
- *   obs   out, T[M][2][A][4], or tiles with SCCBF_FLAG_OBS_TILED in flags
+ *   obs   out, T[M][2][A][4], or tiles / per-agent lists with SCCBF_FLAG_OBS_TILED / _AGENT_MAJOR in flags
  */
 int sccbf_ingest_bbox_f32(int64_t A, int32_t M, const float* bbox, const uint8_t* kind,
                           double buffer, uint32_t flags, float* obs, void* stream);
@@ -520,7 +530,7 @@ int sccbf_ingest_bbox_f64(int64_t A, int32_t M, const double* bbox, const uint8_
  * evaluated once, in double precision, and obs_type is rewritten to the prepared kinds.  Other
  * kinds and already prepared slots are left as they are.  Call it when obstacles change, not per
  * tick; sccbf_ingest_bbox_* writes prepared slots directly when `kind` names them.
- *   obs       in/out, layout by flags: planes, SCCBF_FLAG_OBS_TILED or SCCBF_FLAG_OBS_SHARED
+ *   obs       in/out, layout by flags: planes, SCCBF_FLAG_OBS_TILED, _AGENT_MAJOR or _SHARED
  *   obs_type  in/out, u8[M] or u8[M][A] with SCCBF_FLAG_TYPE_PER_AGENT
  * A prepared cone keeps the beta it was prepared with (SCCBF_FLAG_CONE_BETA_STATE does not
  * reach it).
@@ -539,7 +549,7 @@ int sccbf_prepare_obs_f64(int64_t A, int32_t M, double* obs, uint8_t* obs_type, 
  *                     fixed points are points with a small sigma (alpha = 0.01, 753-756); a
  *                     point with sigma <= 0 or a non-finite value is skipped (ragged counts)
  *   obs     in/out: only slot m (0 <= m < M) is written, c0..c3 | buffer, 0, 0, 0; layout as in
- *           sccbf_solve_* (planes, or tiles with SCCBF_FLAG_OBS_TILED in flags)
+ *           sccbf_solve_* (planes, or SCCBF_FLAG_OBS_TILED / _AGENT_MAJOR in flags)
  * Fewer usable points than coefficients, or points that do not determine them: NaN coefficients
  * (the filter then reports SCCBF_STATUS_NONFINITE for that agent).
  */

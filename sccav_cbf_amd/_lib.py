@@ -17,6 +17,7 @@ OBS_LANE6 = 8                            # a lane polynomial of degree up to 6: 
 DYN_DBM, DYN_KBM, DYN_DUM, DYN_SADBM = 0, 1, 2, 3
 STATUS_OPTIMAL, STATUS_INFEASIBLE, STATUS_NONFINITE = 0, 1, 2
 FLAG_OBS_SHARED, FLAG_TYPE_PER_AGENT, FLAG_SLIP_IO, FLAG_OBS_TILED = 1, 2, 4, 8
+FLAG_OBS_AGENT_MAJOR = 128
 FLAG_CONE_BETA_STATE = 16
 FLAG_OBS_STREAMED = 32
 FLAG_INFEASIBLE_MIN_VIOLATION = 64

@@ -79,7 +79,8 @@ class BatchedCBF:
               want_rows=False, slip=None, dt=None, cone_beta_state=False, step_dt=None,
               max_steer=np.radians(30.0), beta_out=None):
         """state (A,4), u_ref (A,2), obs (M,2,A,4) [or (ceil(A/64),M,2,64,4): tiles of 64 agents,
-        see pack_obs_tiled; or (M,2,4): one table shared by all agents], obs_type uint8 (M,)
+        see pack_obs_tiled; or (A,M,2,4): per-agent lists, the layout for more than 128 slots, see
+        planes_to_agents; or (M,2,4): one table shared by all agents], obs_type uint8 (M,)
         [or (M,A)].  Returns (u_out (A,2), status (A,) int32)
         and, with want_rows/rows_out, rows (M,A,4) = Lg_h0, Lg_h1, b, h.
         dynamics "sadbm": slip (A,2) = beta, beta_ref_last is read and updated in place, dt is the
@@ -102,17 +103,9 @@ class BatchedCBF:
         if dt not in (torch.float32, torch.float64):
             raise TypeError("state must be float32 or float64")
         A = state.shape[0]
-        M = obs.shape[1] if obs.dim() == 5 else obs.shape[0]
         dev = state.device
-        flags = (FLAG_SLIP_IO if self.slip_io else 0) | (_lib.FLAG_OBS_STREAMED if self.streamed_obs else 0)
-        if obs.dim() == 5:
-            flags |= FLAG_OBS_TILED
-            exp_obs = ((A + 63) // 64, M, 2, 64, 4)
-        elif obs.dim() == 3:
-            flags |= FLAG_OBS_SHARED
-            exp_obs = (M, 2, 4)
-        else:
-            exp_obs = (M, 2, A, 4)
+        lflag, M, exp_obs = obs_layout(obs, A)
+        flags = lflag | (FLAG_SLIP_IO if self.slip_io else 0) | (_lib.FLAG_OBS_STREAMED if self.streamed_obs else 0)
         if obs_type.dim() == 2:
             flags |= FLAG_TYPE_PER_AGENT
             exp_ty = (M, A)
@@ -270,15 +263,14 @@ class BatchTable:
         self.dtype, self.device = b0["state"].dtype, b0["state"].device
         if self.dtype not in (torch.float32, torch.float64):
             raise TypeError("state must be float32 or float64")
-        od, td = b0["obs"].dim(), b0["obs_type"].dim()
-        self.M = b0["obs"].shape[1] if od == 5 else b0["obs"].shape[0]
-        self.flags = ({5: FLAG_OBS_TILED, 3: FLAG_OBS_SHARED}.get(od, 0)
-                      | (FLAG_TYPE_PER_AGENT if td == 2 else 0))
+        td = b0["obs_type"].dim()
+        lflag, self.M, _ = obs_layout(b0["obs"], b0["state"].shape[0])
+        self.flags = lflag | (FLAG_TYPE_PER_AGENT if td == 2 else 0)
         dt, dev, M = self.dtype, self.device, self.M
         rec = np.zeros((len(batches), 8), dtype=np.int64)
         for i, b in enumerate(batches):
             A = b["state"].shape[0]
-            exp_obs = {5: ((A + 63) // 64, M, 2, 64, 4), 3: (M, 2, 4)}.get(od, (M, 2, A, 4))
+            exp_obs = obs_shape(lflag, A, M)
             b.setdefault("u_out", torch.empty((A, 2), dtype=dt, device=dev))
             b.setdefault("status", torch.empty((A,), dtype=torch.int32, device=dev))
             if want_rows:
@@ -317,26 +309,19 @@ def prewarm():
 
 def prepare_obs(obs, obs_type, agents=None):
     """As-written ellipse / cone slots -> prepared slots (kinds 4 and 5), IN PLACE on the GPU
-    (sccbf_prepare_obs_*): obs in any of the three layouts, obs_type (M,) or (M, A) uint8 is
+    (sccbf_prepare_obs_*): obs in any of the four layouts, obs_type (M,) or (M, A) uint8 is
     rewritten to the prepared kinds.  agents: A, needed for tiles whose last tile is partly unused
-    (default: every lane of every tile).  Call it when obstacles change; the filter then does no
+    (default: every lane of every tile) and for per-agent lists of two slots.  Call it when obstacles change; the filter then does no
     sine, cosine or reciprocal per slot and tick.  Returns (obs, obs_type)."""
     if not obs.is_cuda:
         raise _lib.SccbfError("prepare_obs needs tensors on the GPU (no CPU fallback)")
     lib = _lib.load()
     dt, dev = obs.dtype, obs.device
-    flags = 0
-    if obs.dim() == 5:
-        flags |= FLAG_OBS_TILED
-        M, A = obs.shape[1], obs.shape[0] * 64 if agents is None else int(agents)
-        exp = ((A + 63) // 64, M, 2, 64, 4)
-    elif obs.dim() == 3:
-        flags |= FLAG_OBS_SHARED
-        M, A = obs.shape[0], 1
-        exp = (M, 2, 4)
+    flags, M, exp = obs_layout(obs, agents)
+    if flags == FLAG_OBS_TILED:
+        A = obs.shape[0] * 64 if agents is None else int(agents)
     else:
-        M, A = obs.shape[0], obs.shape[2]
-        exp = (M, 2, A, 4)
+        A = {FLAG_OBS_SHARED: 1, _lib.FLAG_OBS_AGENT_MAJOR: obs.shape[0]}.get(flags, obs.shape[2])
     if obs_type.dim() == 2:
         flags |= FLAG_TYPE_PER_AGENT
         exp_ty = (M, A)
@@ -399,6 +384,42 @@ def pack_obs_tiled(slots):
     out = slots.new_zeros((T * 64, M, 2, 4))
     out[:A] = slots.reshape(M, A, 2, 4).permute(1, 0, 2, 3)
     return out.reshape(T, 64, M, 2, 4).permute(0, 2, 3, 1, 4).contiguous()
+
+
+def obs_shape(layout_flag, A, M):
+    """Shape of obs for A agents and M slots in the layout a flag names (0: planes)."""
+    return {FLAG_OBS_TILED: ((A + 63) // 64, M, 2, 64, 4), FLAG_OBS_SHARED: (M, 2, 4),
+            _lib.FLAG_OBS_AGENT_MAJOR: (A, M, 2, 4)}.get(layout_flag, (M, 2, A, 4))
+
+
+def obs_layout(obs, A=None):
+    """The layout of an obstacle tensor by its shape -> (layout flag, M, the shape it should have for A agents):
+    (ceil(A/64),M,2,64,4) tiles, (M,2,4) one shared table, (M,2,A,4) planes, (A,M,2,4) per-agent lists.  A
+    four-dimensional tensor that fits both readings (A = M = 2, or two slots with A unknown) is read as
+    planes."""
+    if not torch.is_tensor(obs) or obs.dim() not in (3, 4, 5):
+        raise ValueError("obs: expected planes (M,2,A,4), tiles (ceil(A/64),M,2,64,4), per-agent lists "
+                         "(A,M,2,4) or a shared table (M,2,4)")
+    if obs.dim() == 5:
+        flag, M = FLAG_OBS_TILED, obs.shape[1]
+    elif obs.dim() == 3:
+        flag, M = FLAG_OBS_SHARED, obs.shape[0]
+    elif obs.shape[1] == 2 and (A is None or obs.shape[2] == A):
+        flag, M = 0, obs.shape[0]
+    elif obs.shape[2] == 2:
+        flag, M = _lib.FLAG_OBS_AGENT_MAJOR, obs.shape[1]
+    else:
+        flag, M = 0, obs.shape[0]
+    if A is None:
+        A = {FLAG_OBS_TILED: obs.shape[0] * 64, FLAG_OBS_SHARED: 1,
+             _lib.FLAG_OBS_AGENT_MAJOR: obs.shape[0]}.get(flag, obs.shape[2])
+    return flag, M, obs_shape(flag, int(A), M)
+
+
+def planes_to_agents(obs):
+    """(M, 2, A, 4) -> (A, M, 2, 4): every agent's slots side by side (SCCBF_FLAG_OBS_AGENT_MAJOR), the layout
+    that lists of more than 128 slots stream fastest from."""
+    return obs.permute(2, 0, 1, 3).contiguous()
 
 
 def planes_to_tiled(obs):

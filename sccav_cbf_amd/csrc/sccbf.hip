@@ -98,6 +98,14 @@ void launch_(void (*kernel)(P...), dim3 grid, dim3 block, size_t lds, hipStream_
 // SCCBF_OK or SCCBF_ERR_LAUNCH of the calling thread's latest launch_()
 inline int launched_() { return t_launch_rc; }
 
+// obs is laid out one way: at most one of the layout flags
+constexpr uint32_t kObsLayoutFlags = SCCBF_FLAG_OBS_SHARED | SCCBF_FLAG_OBS_TILED | SCCBF_FLAG_OBS_AGENT_MAJOR;
+inline bool one_obs_layout_(uint32_t flags)
+{
+    const uint32_t l = flags & kObsLayoutFlags;
+    return (l & (l - 1)) == 0;
+}
+
 template <typename T>
 int fill_args(const sccbf_params* sp, int64_t A, int32_t M, KArgs<T>& k)
 {
@@ -107,7 +115,7 @@ int fill_args(const sccbf_params* sp, int64_t A, int32_t M, KArgs<T>& k)
     if (sp->dynamics != SCCBF_DYN_DBM && sp->dynamics != SCCBF_DYN_KBM && sp->dynamics != SCCBF_DYN_DUM &&
         sp->dynamics != SCCBF_DYN_SADBM)
         return SCCBF_ERR_ARG;
-    if ((sp->flags & SCCBF_FLAG_OBS_SHARED) && (sp->flags & SCCBF_FLAG_OBS_TILED)) return SCCBF_ERR_ARG;
+    if (!one_obs_layout_(sp->flags)) return SCCBF_ERR_ARG;
     const double r00 = sp->R[0], r01 = 0.5 * (sp->R[1] + sp->R[2]), r11 = sp->R[3];
     if (!(r00 > 0.0) || !std::isfinite(r00) || !std::isfinite(r01) || !std::isfinite(r11))
         return SCCBF_ERR_WEIGHT;
@@ -191,15 +199,15 @@ template <typename T, int G> struct WaveShape {
     static constexpr int kQpb = G == 16 ? 16 : (G == 32 ? 8 : (sizeof(T) == 4 ? 8 : 4));
 };
 
-template <typename T> size_t wave_lds(int M, int qpb) { return wave_lds_bytes<T>(M, qpb); }
+template <typename T> size_t wave_lds(int M, int qpb, int G) { return wave_lds_bytes<T>(M, qpb, G); }
 
 // lanes per QP when the library chooses (measured at 65536 agents, fp32, 129 ... 1024 rows): the narrowest
-// group of which four workgroups still fit a CU (16 lanes up to 213 fp32 rows, 32 up to 416), else a
+// group of which four workgroups still fit a CU (16 lanes up to 208 fp32 rows, 32 up to 416), else a
 // wavefront per QP, whose workgroups have twice the wavefronts for the same tables
 template <typename T> int wave_lanes(int M)
 {
-    if (wave_lds<T>(M, WaveShape<T, 16>::kQpb) * 4 <= kLdsPerCu) return 16;
-    if (wave_lds<T>(M, WaveShape<T, 32>::kQpb) * 4 <= kLdsPerCu) return 32;
+    if (wave_lds<T>(M, WaveShape<T, 16>::kQpb, 16) * 4 <= kLdsPerCu) return 16;
+    if (wave_lds<T>(M, WaveShape<T, 32>::kQpb, 32) * 4 <= kLdsPerCu) return 32;
     return 64;
 }
 
@@ -232,12 +240,12 @@ template <int QPB, bool PAIRED> long long wave_blocks(long long A)
 
 // two workgroups of a line's worth of tables (eight fp32 agents, four fp64) no longer fit a CU: half of
 // them per workgroup, paired on an XCD
-template <typename T> bool wave_paired(int M) { return wave_lds<T>(M, WaveShape<T, 64>::kQpb) * 2 > kLdsPerCu; }
+template <typename T> bool wave_paired(int M) { return wave_lds<T>(M, WaveShape<T, 64>::kQpb, 64) * 2 > kLdsPerCu; }
 
 template <typename T, bool QP_ONLY, int G, int QPB, bool PAIRED>
 int launch_wave_shape(const KArgs<T>& k, hipStream_t s)
 {
-    const size_t lds = wave_lds<T>(k.M, QPB);
+    const size_t lds = wave_lds<T>(k.M, QPB, G);
     const long long blocks = wave_blocks<QPB, PAIRED>(k.A);
     if (blocks > 0x7fffffffLL) return SCCBF_ERR_ARG;
     if (!grant_lds<k_wave<T, QPB, QP_ONLY, G, PAIRED>>(lds)) return SCCBF_ERR_VARIANT;
@@ -300,7 +308,7 @@ int launch_ext_rpl(const KArgs<T>& k, const XArgs<T>& x, hipStream_t s)
 template <typename T, int G, int QPB, bool PAIRED>
 int launch_wave_ext_shape(const KArgs<T>& k, const XArgs<T>& x, hipStream_t s)
 {
-    const size_t lds = wave_lds<T>(k.M, QPB);
+    const size_t lds = wave_lds<T>(k.M, QPB, G);
     const long long blocks = wave_blocks<QPB, PAIRED>(k.A);
     if (blocks > 0x7fffffffLL) return SCCBF_ERR_ARG;
     if (!grant_lds<k_wave_ext<T, QPB, G, PAIRED>>(lds)) return SCCBF_ERR_VARIANT;
@@ -617,7 +625,8 @@ int ingest_impl(int64_t A, int32_t M, const T* bbox, const uint8_t* kind, double
                 T* obs, void* stream)
 {
     if (A < 0 || M < 0 || A > 0x7fffffffLL || M > SCCBF_MAX_ROWS || !std::isfinite(buffer)) return SCCBF_ERR_ARG;
-    if (flags & ~(SCCBF_FLAG_TYPE_PER_AGENT | SCCBF_FLAG_OBS_TILED)) return SCCBF_ERR_ARG;
+    if (flags & ~(SCCBF_FLAG_TYPE_PER_AGENT | SCCBF_FLAG_OBS_TILED | SCCBF_FLAG_OBS_AGENT_MAJOR)) return SCCBF_ERR_ARG;
+    if (!one_obs_layout_(flags)) return SCCBF_ERR_ARG;
     if (A == 0 || M == 0) return SCCBF_OK;
     if (!bbox || !kind || !obs) return SCCBF_ERR_ARG;
     IArgs<T> k;
@@ -633,8 +642,8 @@ template <typename T>
 int prepare_impl(int64_t A, int32_t M, T* obs, uint8_t* obs_type, uint32_t flags, void* stream)
 {
     if (A < 0 || M < 0 || A > 0x7fffffffLL || M > SCCBF_MAX_ROWS) return SCCBF_ERR_ARG;
-    if (flags & ~(SCCBF_FLAG_TYPE_PER_AGENT | SCCBF_FLAG_OBS_TILED | SCCBF_FLAG_OBS_SHARED)) return SCCBF_ERR_ARG;
-    if ((flags & SCCBF_FLAG_OBS_SHARED) && (flags & (SCCBF_FLAG_OBS_TILED | SCCBF_FLAG_TYPE_PER_AGENT)))
+    if (flags & ~(SCCBF_FLAG_TYPE_PER_AGENT | kObsLayoutFlags)) return SCCBF_ERR_ARG;
+    if (!one_obs_layout_(flags) || ((flags & SCCBF_FLAG_OBS_SHARED) && (flags & SCCBF_FLAG_TYPE_PER_AGENT)))
         return SCCBF_ERR_ARG;
     if (A == 0 || M == 0) return SCCBF_OK;
     if (!obs || !obs_type) return SCCBF_ERR_ARG;
@@ -657,7 +666,7 @@ int lane_fit_impl(int64_t A, int32_t K, int32_t degree, const T* px, const T* py
 {
     if (A < 0 || A > 0x7fffffffLL || K < 1 || degree < 0 || degree > 3 || !std::isfinite(buffer)) return SCCBF_ERR_ARG;
     if (M < 1 || M > SCCBF_MAX_ROWS || m < 0 || m >= M) return SCCBF_ERR_ARG;
-    if (flags & ~SCCBF_FLAG_OBS_TILED) return SCCBF_ERR_ARG;
+    if ((flags & ~(SCCBF_FLAG_OBS_TILED | SCCBF_FLAG_OBS_AGENT_MAJOR)) || !one_obs_layout_(flags)) return SCCBF_ERR_ARG;
     if (A == 0) return SCCBF_OK;
     if (!px || !py || !obs) return SCCBF_ERR_ARG;
     FArgs<T> k;
@@ -716,7 +725,7 @@ int launch_group_batches_rpl(const KArgs<T>& k, const sccbf_batch* table, int K,
 template <typename T, int G, int QPB, bool PAIRED>
 int launch_wave_batches_shape(const KArgs<T>& k, const sccbf_batch* table, int K, long long a_max, hipStream_t s)
 {
-    const size_t lds = wave_lds<T>(k.M, QPB);
+    const size_t lds = wave_lds<T>(k.M, QPB, G);
     const long long bx = wave_blocks<QPB, PAIRED>(a_max);
     if (bx > 0x7fffffffLL) return SCCBF_ERR_ARG;
     if (!grant_lds<k_wave_batches<T, QPB, G, PAIRED>>(lds)) return SCCBF_ERR_VARIANT;

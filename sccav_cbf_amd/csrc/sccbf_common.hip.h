@@ -219,6 +219,7 @@ template <> struct Lim<float> {
     static constexpr float par_tol = 1e-6f;    // |sin| below this = parallel rows
     static constexpr float feas_tol = 1e-6f;   // relative slack of the "bounds cross" test
     static constexpr float lane_xtol = 3e-4f;
+    static constexpr float big = 3.0e38f;      // finite, beyond every bound a row can state
 };
 template <> struct Lim<double> {
     static constexpr double eps = 2.220446049250313e-16;
@@ -227,6 +228,7 @@ template <> struct Lim<double> {
     static constexpr double par_tol = 1e-14;
     static constexpr double feas_tol = 1e-10;
     static constexpr double lane_xtol = 1e-8;
+    static constexpr double big = 1.0e300;
 };
 
 // ------------------------------------------------------------- cross-lane helpers

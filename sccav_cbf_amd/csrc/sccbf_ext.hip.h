@@ -205,8 +205,8 @@ __global__ __launch_bounds__(QPB * G) __attribute__((amdgpu_waves_per_eu(kWaveWa
     extern __shared__ __align__(16) unsigned char smem_raw[];
     static_assert(QPB * G % 64 == 0, "whole wavefronts");
     const int M = p.M;
-    const WaveTables<T> tab(smem_raw, M, QPB);
-    const int stride = wave_table_stride(M);
+    const WaveTables<T> tab(smem_raw, M, QPB, G);
+    const int stride = wave_table_stride(M, G);
     const int qa = (int)(threadIdx.x % QPB), rsub = (int)(threadIdx.x / QPB);  // forming rows
     const int qs = (int)(threadIdx.x / G), g = (int)(threadIdx.x % G);         // solving
 
@@ -220,25 +220,22 @@ __global__ __launch_bounds__(QPB * G) __attribute__((amdgpu_waves_per_eu(kWaveWa
     int bad = q.bad;
     __syncthreads();
 
-    T* r_at0 = tab.rows + (size_t)qa * stride;
-    T* r_at1 = r_at0 + M;
-    T* r_bt = r_at1 + M;
+    T* table = tab.rows + (size_t)qa * stride;
+    T chk = T(0);  // stays 0 while every row is finite
     staged_rows_<T, G, false>(p, qp, rsub, [&](int m, const v4& oa, const v4& ob, int ty) {
         T o[8] = {oa.x, oa.y, oa.z, oa.w, ob.x, ob.y, ob.z, ob.w};
         T a0, a1, b, h;
         ext_slot_row_(ty, o, q.e, p, q.sadbm, q.cone_beta_state, q.sl.x, q.cthb, q.sthb, q.sb, a0, a1, b, h);
         if (p.rows_out && live) reinterpret_cast<v4*>(p.rows_out)[(long long)m * p.A + qp] = v4{a0, a1, b, h};
-        bad |= !(finite_(a0) && finite_(a1) && finite_(b));
+        chk += a0 * T(0) + a1 * T(0) + b * T(0);
         T t0, t1, tb;
         to_wspace_(a0, a1, b, q.e, p, t0, t1, tb);
-        r_at0[m] = t0;
-        r_at1[m] = t1;
-        r_bt[m] = tb;
+        wave_table_put(table, m, t0, t1, tb);
     });
-    if (bad) tab.bad[qa] = 1;
+    wave_table_pad<T, G>(table, M, rsub);
+    if (bad | !(chk == T(0))) tab.bad[qa] = 1;
     __syncthreads();
-    const T* s_at0 = tab.rows + (size_t)qs * stride;
-    const Pivot<T> s = wave_active_set_<T, G>(M, g, s_at0, s_at0 + M, s_at0 + 2 * M, tab.bad[qs]);
+    const Pivot<T> s = wave_active_set_<T, G>(M, g, tab.rows + (size_t)qs * stride, tab.bad[qs]);
     if (g == 0) {
         tab.answer[2 * qs] = s.w0;
         tab.answer[2 * qs + 1] = s.w1;

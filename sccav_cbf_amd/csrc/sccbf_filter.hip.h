@@ -225,45 +225,74 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kGroupWa
 }
 
 // ------------------------------------------ rows staged in LDS only: any M up to SCCBF_MAX_ROWS
-// The active-set iteration of a group of G lanes (16, 32 or the whole wavefront) on the M rows it has
-// staged in LDS: every lane scans rows g, g + G, ..., the most violated row comes from a max over the
-// group, the pivot reads it by index (broadcast reads).  The trip count is wave-uniform; the groups
-// of a wavefront commit under `go`.
+// Table of one QP in LDS: row m at words 3 m, 3 m + 1, 3 m + 2 (at0, at1, bt), M rounded up to whole turns of
+// the G lanes that scan it; the rows past M are (0, 0, -max): never violated.  Words between the tables of two
+// QPs of a workgroup: odd, so that the groups of a wavefront scan different banks.
+__host__ __device__ inline int wave_table_rows(int M, int G) { return (M + G - 1) / G * G; }
+__host__ __device__ inline int wave_table_stride(int M, int G) { return (3 * wave_table_rows(M, G)) | 1; }
+
+// The active-set iteration of a group of G lanes (16, 32 or the whole wavefront) on the rows it has staged
+// in LDS: every lane scans rows g, g + G, ... (the same number for every lane, no lane masked: the offsets
+// of an unrolled turn are immediates of the reads, and the loop counter is scalar), the most violated row
+// comes from a max over the group, the pivot reads it by index (broadcast reads).  Keys as in active_set_:
+// violation in the high bits, 1023 - row below, compared as signed integers; the threshold is applied once, to
+// the winner.  The trip count is wave-uniform; the groups of a wavefront commit under `go`.
 template <typename T, int G>
-__device__ inline Pivot<T> wave_active_set_(int M, int g, const T* s_at0, const T* s_at1, const T* s_bt, int bad)
+__device__ inline Pivot<T> wave_active_set_(int M, int g, const T* s_rows, int bad)
 {
     Pivot<T> s;
     s.reset(bad ? SCCBF_STATUS_NONFINITE : SCCBF_STATUS_OPTIMAL);
     const int cap = kCapPerRow * M + kCapBase;
+    const int turns = (M + G - 1) / G;
+    const T* mine = s_rows + 3 * g;
     for (int it = 0;; ++it) {  // wave-uniform loop
         const T thr = Lim<T>::viol_tol * (abs_(s.w0) + abs_(s.w1)) + Lim<T>::tiny_n2;
-        unsigned kbest = 0u;
-        for (int m = g; m < M; m += G) {
-            const T viol = s_bt[m] - (s_at0[m] * s.w0 + s_at1[m] * s.w1);
-            const unsigned key = viol > thr ? ((viol_bits_pos(viol) & ~0x3FFu) | (unsigned)(1023 - m)) : 0u;
+        int kbest = (int)0x80000000u;
+#pragma unroll 4
+        for (int i = 0; i < turns; ++i) {
+            const T* r = mine + 3 * G * i;
+            const T viol = r[2] - (r[0] * s.w0 + r[1] * s.w1);
+            const int key = (int)((viol_bits(viol, thr) & ~0x3FFu) | (unsigned)(1023 - g - G * i));
             kbest = key > kbest ? key : kbest;
         }
-        const unsigned kmax = group_umax<G>(kbest);
-        const bool go = (s.st == SCCBF_STATUS_OPTIMAL) & (kmax != 0u);
+        const int kmax = group_imax<G>(kbest);
+        const bool go = (s.st == SCCBF_STATUS_OPTIMAL) & viol_key_above(kmax, thr, 0x3FFu);
         if (!__any(go)) break;  // every group of the wavefront is done
         if (it >= cap) {
             s.st = go ? SCCBF_STATUS_INFEASIBLE : s.st;
             break;
         }
-        const int sel = go ? 1023 - (int)(kmax & 0x3FFu) : 0;
-        pivot_onto_(s, s_at0[sel], s_at1[sel], s_bt[sel], go);  // broadcast reads
+        const T* w = s_rows + 3 * (go ? 1023 - (kmax & 0x3FF) : 0);
+        pivot_onto_(s, w[0], w[1], w[2], go);  // broadcast reads
     }
     return s;
 }
 
-// LDS words between the row tables of two QPs of a workgroup: odd, so that the groups of a wavefront
-// scan different banks
-__host__ __device__ inline int wave_table_stride(int M) { return (3 * M) | 1; }
+// The forming side of the same table: row m of the QP whose table starts at `table`.
+template <typename T> __device__ inline void wave_table_put(T* table, int m, T t0, T t1, T tb)
+{
+    table[3 * m] = t0;
+    table[3 * m + 1] = t1;
+    table[3 * m + 2] = tb;
+}
+// Thread `rsub` of the G that form a QP's rows fills its share of the padding (fewer than G rows).
+template <typename T, int G> __device__ inline void wave_table_pad(T* table, int M, int rsub)
+{
+    const int m = M + rsub;
+    if (m < wave_table_rows(M, G)) wave_table_put(table, m, T(0), T(0), -Lim<T>::big);
+}
 
 // The slots of a lane (g, g + G, ...) come kWaveBatch at a time, and the next batch is on its way while the
 // rows of the current one are formed: with the few wavefronts per CU that the row tables leave room for, a
 // wavefront has to overlap its own loads and arithmetic.  row(m, oa, ob, ty) forms and stores row m.
-constexpr int kWaveBatch = 4;
+// Two slots per batch (measured against 1, 4 and 8 at 129 ... 1024 rows): the row code is inlined once per
+// slot of the two batches, four copies, the kernels stay within 96 registers (five wavefronts per SIMD) and
+// spill nothing; four per batch take 128 registers and are 8 % slower, eight (80 KB of code, more than the
+// instruction cache holds) three times slower.
+#ifndef SCCBF_WAVE_BATCH
+#define SCCBF_WAVE_BATCH 2
+#endif
+constexpr int kWaveBatch = SCCBF_WAVE_BATCH;
 template <typename T> struct SlotBatch {
     typename VT<T>::v4 oa[kWaveBatch], ob[kWaveBatch];
     int ty[kWaveBatch];
@@ -325,21 +354,21 @@ __device__ inline void staged_rows_(const KArgs<T>& p, long long qp, int g, RowF
 // state (t < QPB), which stores it.  A CU should hold at least two workgroups: while one iterates, the other
 // loads; one alone leaves the memory idle for a quarter of the time.
 template <typename T> struct WaveTables {
-    T* rows;      // QPB tables of wave_table_stride(M) values: at0[M], at1[M], bt[M]
+    T* rows;      // QPB tables of wave_table_stride(M, G) values
     T* answer;    // QPB x (w0, w1)
     int* status;  // QPB
     int* bad;     // QPB
-    __device__ WaveTables(unsigned char* raw, int M, int qpb)
+    __device__ WaveTables(unsigned char* raw, int M, int qpb, int G)
     {
         rows = reinterpret_cast<T*>(raw);
-        answer = rows + (size_t)qpb * wave_table_stride(M);
+        answer = rows + (size_t)qpb * wave_table_stride(M, G);
         status = reinterpret_cast<int*>(answer + 2 * qpb);
         bad = status + qpb;
     }
 };
-template <typename T> __host__ __device__ inline size_t wave_lds_bytes(int M, int qpb)
+template <typename T> __host__ __device__ inline size_t wave_lds_bytes(int M, int qpb, int G)
 {
-    return ((size_t)qpb * wave_table_stride(M) + 2 * qpb) * sizeof(T) + 2 * qpb * sizeof(int);
+    return ((size_t)qpb * wave_table_stride(M, G) + 2 * qpb) * sizeof(T) + 2 * qpb * sizeof(int);
 }
 
 // First agent of a workgroup.  PAIRED: the workgroup takes half of the agents that share a line, and the
@@ -364,8 +393,8 @@ __device__ inline void wave_body_(const KArgs<T>& p, unsigned block, unsigned ch
     static_assert(QPB * G % 64 == 0, "whole wavefronts");
     constexpr int RS = G;  // rows of an agent formed side by side
     const int M = p.M;
-    const WaveTables<T> tab(smem_raw, M, QPB);
-    const int stride = wave_table_stride(M);
+    const WaveTables<T> tab(smem_raw, M, QPB, G);
+    const int stride = wave_table_stride(M, G);
     const int qa = (int)(threadIdx.x % QPB), rsub = (int)(threadIdx.x / QPB);  // forming rows
     const int qs = (int)(threadIdx.x / G), g = (int)(threadIdx.x % G);         // solving
 
@@ -380,9 +409,8 @@ __device__ inline void wave_body_(const KArgs<T>& p, unsigned block, unsigned ch
     load_ego_(p, qp, QP_ONLY, e, ur0, ur1, bad);
     __syncthreads();
 
-    T* r_at0 = tab.rows + (size_t)qa * stride;
-    T* r_at1 = r_at0 + M;
-    T* r_bt = r_at1 + M;
+    T* table = tab.rows + (size_t)qa * stride;
+    T chk = T(0);  // stays 0 while every row is finite
     staged_rows_<T, RS, QP_ONLY>(p, qp, rsub, [&](int m, const v4& oa, const v4& ob, int ty) {
         T a0, a1, b, h;
         if (QP_ONLY) {
@@ -392,17 +420,15 @@ __device__ inline void wave_body_(const KArgs<T>& p, unsigned block, unsigned ch
             slot_row_(ty, o, e, p, a0, a1, b, h);
             if (p.rows_out && live) reinterpret_cast<v4*>(p.rows_out)[(long long)m * p.A + qp] = v4{a0, a1, b, h};
         }
-        bad |= !(finite_(a0) && finite_(a1) && finite_(b));
+        chk += a0 * T(0) + a1 * T(0) + b * T(0);
         T t0, t1, tb;
         to_wspace_(a0, a1, b, e, p, t0, t1, tb);
-        r_at0[m] = t0;
-        r_at1[m] = t1;
-        r_bt[m] = tb;
+        wave_table_put(table, m, t0, t1, tb);
     });
-    if (bad) tab.bad[qa] = 1;
+    wave_table_pad<T, G>(table, M, rsub);
+    if (bad | !(chk == T(0))) tab.bad[qa] = 1;
     __syncthreads();
-    const T* s_at0 = tab.rows + (size_t)qs * stride;
-    const Pivot<T> s = wave_active_set_<T, G>(M, g, s_at0, s_at0 + M, s_at0 + 2 * M, tab.bad[qs]);
+    const Pivot<T> s = wave_active_set_<T, G>(M, g, tab.rows + (size_t)qs * stride, tab.bad[qs]);
     if (g == 0) {
         tab.answer[2 * qs] = s.w0;
         tab.answer[2 * qs + 1] = s.w1;
@@ -413,9 +439,12 @@ __device__ inline void wave_body_(const KArgs<T>& p, unsigned block, unsigned ch
         store_result_(p, qp, QP_ONLY, tab.status[qa], tab.answer[2 * qa], tab.answer[2 * qa + 1], e, ur0, ur1);
 }
 
-// The fp32 kernels of this family sit at 118 ... 130 registers: held to the 128 of four wavefronts per SIMD (two
-// workgroups of eight wavefronts per CU while one forms rows and the other iterates); fp64 is left alone.
-template <typename T> constexpr int kWaveWaves = sizeof(T) == 4 ? 4 : 1;
+// Wavefronts per SIMD the register allocation of this family is held to (at least): the fp32 kernels sit at
+// 94 ... 100 registers, the 96 of five wavefronts within reach; fp64 is left alone.
+#ifndef SCCBF_WAVE_WAVES_F32
+#define SCCBF_WAVE_WAVES_F32 5
+#endif
+template <typename T> constexpr int kWaveWaves = sizeof(T) == 4 ? SCCBF_WAVE_WAVES_F32 : 1;
 
 template <typename T, int QPB, bool QP_ONLY, int G, bool PAIRED = false>
 __global__ __launch_bounds__(QPB * G) __attribute__((amdgpu_waves_per_eu(kWaveWaves<T>))) void k_wave(const KArgs<T> p)

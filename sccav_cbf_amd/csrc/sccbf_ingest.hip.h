@@ -8,7 +8,7 @@ namespace {
 template <typename T> struct IArgs {
     long long A;
     int M;
-    unsigned flags;      // SCCBF_FLAG_TYPE_PER_AGENT (kind), SCCBF_FLAG_OBS_TILED (layout of obs)
+    unsigned flags;      // SCCBF_FLAG_TYPE_PER_AGENT (kind), SCCBF_FLAG_OBS_TILED / _AGENT_MAJOR (layout of obs)
     const T* bbox;       // [M][2][A][4] = loc_x, loc_y, ext_x, ext_y | yaw, speed, -, -
     const uint8_t* kind; // [M] or [M][A]
     T buffer;
@@ -19,7 +19,7 @@ template <typename T> struct IArgs {
 template <typename T> __device__ inline ObsAddr slot_addr_(long long A, int M, unsigned flags, long long a)
 {
     KArgs<T> k;
-    k.A = A; k.M = M; k.flags = flags & SCCBF_FLAG_OBS_TILED;
+    k.A = A; k.M = M; k.flags = flags & (SCCBF_FLAG_OBS_TILED | SCCBF_FLAG_OBS_AGENT_MAJOR);
     return obs_addr_(k, a);
 }
 
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(kBlock) void k_prepare_obs(const PArgs<T> p)
     const int kind = (p.flags & SCCBF_FLAG_TYPE_PER_AGENT) ? p.type[(long long)m * p.A + a] : p.type[m];
     if (kind != SCCBF_OBS_ELLIPSE && kind != SCCBF_OBS_CONE) return;
     KArgs<T> k;
-    k.A = p.A; k.M = p.M; k.flags = p.flags & (SCCBF_FLAG_OBS_TILED | SCCBF_FLAG_OBS_SHARED);
+    k.A = p.A; k.M = p.M; k.flags = p.flags & (SCCBF_FLAG_OBS_TILED | SCCBF_FLAG_OBS_SHARED | SCCBF_FLAG_OBS_AGENT_MAJOR);
     const ObsAddr ad = obs_addr_(k, a);
     v4* obs = reinterpret_cast<v4*>(p.obs);
     v4 oa = obs[ad.at(m)], ob = obs[ad.at(m) + ad.half];

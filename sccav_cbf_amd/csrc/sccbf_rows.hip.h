@@ -307,10 +307,17 @@ template <typename T> __device__ inline ObsAddr obs_addr_(const KArgs<T>& p, lon
     ObsAddr r;
     const bool shared = (p.flags & SCCBF_FLAG_OBS_SHARED) != 0;
     const bool tiled = (p.flags & SCCBF_FLAG_OBS_TILED) != 0;
-    r.base = shared ? 0ull : (tiled ? (unsigned long long)(a / kTile) * (unsigned)(2 * kTile * p.M) + (unsigned)(a % kTile)
-                                    : (unsigned long long)a);
-    r.slot = shared ? 2u : (tiled ? 2u * kTile : 2u * (unsigned)p.A);
-    r.half = shared ? 1u : (tiled ? (unsigned)kTile : (unsigned)p.A);
+    const bool by_agent = (p.flags & SCCBF_FLAG_OBS_AGENT_MAJOR) != 0;
+    if (shared || by_agent) {  // the slots of one table, or of one agent, side by side
+        r.base = by_agent ? (unsigned long long)a * (unsigned)(2 * p.M) : 0ull;
+        r.slot = 2u;
+        r.half = 1u;
+        return r;
+    }
+    r.base = tiled ? (unsigned long long)(a / kTile) * (unsigned)(2 * kTile * p.M) + (unsigned)(a % kTile)
+                   : (unsigned long long)a;
+    r.slot = tiled ? 2u * kTile : 2u * (unsigned)p.A;
+    r.half = tiled ? (unsigned)kTile : (unsigned)p.A;
     return r;
 }
 

@@ -12,7 +12,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from .batched import _ptr
+from .batched import _ptr, obs_layout, obs_shape
 
 
 def _need_gpu(t, what):
@@ -28,27 +28,30 @@ def _check(name, t, shape, dtype, dev):
             name, tuple(shape), dtype, dev, tuple(t.shape), t.dtype, t.device))
 
 
-def _obs_shape(A, M, tiled):
-    return ((A + 63) // 64, M, 2, 64, 4) if tiled else (M, 2, A, 4)
+def _layout_flag(tiled, agent_major):
+    if tiled and agent_major:
+        raise ValueError("one layout: tiled or agent_major")
+    return _lib.FLAG_OBS_TILED if tiled else (_lib.FLAG_OBS_AGENT_MAJOR if agent_major else 0)
 
 
-def ingest_bbox(bbox, kind, buffer=0.5, tiled=False, out=None):
+def ingest_bbox(bbox, kind, buffer=0.5, tiled=False, out=None, agent_major=False):
     """bbox (M,2,A,4) = location x, y, extent x, y | yaw, speed, -, -; kind uint8 (M,) or (M,A) with
     OBS_ELLIPSE / OBS_CONE (anything else: an all-zero slot).  Returns obs in the planes layout
-    (M,2,A,4) or, with tiled=True, in 64-agent tiles; `kind` is the obs_type of the solve."""
+    (M,2,A,4) or, with tiled=True, in 64-agent tiles, or, with agent_major=True, as per-agent lists
+    (A,M,2,4); `kind` is the obs_type of the solve."""
     _need_gpu(bbox, "ingest_bbox")
     M, A = bbox.shape[0], bbox.shape[2]
     dev, ty = bbox.device, bbox.dtype
     _check("bbox", bbox, (M, 2, A, 4), ty, dev)
-    flags = _lib.FLAG_OBS_TILED if tiled else 0
+    flags = lflag = _layout_flag(tiled, agent_major)
     if kind.dim() == 2:
         flags |= _lib.FLAG_TYPE_PER_AGENT
         _check("kind", kind, (M, A), torch.uint8, dev)
     else:
         _check("kind", kind, (M,), torch.uint8, dev)
     if out is None:
-        out = torch.zeros(_obs_shape(A, M, tiled), dtype=ty, device=dev)
-    _check("out", out, _obs_shape(A, M, tiled), ty, dev)
+        out = torch.zeros(obs_shape(lflag, A, M), dtype=ty, device=dev)
+    _check("out", out, obs_shape(lflag, A, M), ty, dev)
     lib = _lib.load()
     fn = lib.sccbf_ingest_bbox_f32 if ty == torch.float32 else lib.sccbf_ingest_bbox_f64
     with torch.cuda.device(dev):
@@ -82,7 +85,7 @@ def bbox_as_obs(bbox, kind, buffer=0.5):
 def lane_fit(px, py, obs, slot, sigma=None, degree=3, buffer=1.5):
     """px, py (K,A): lane points of every agent; sigma (K,A) or None (10 everywhere; a fixed point
     is a point with a small sigma, a point with sigma <= 0 is skipped).  Writes lane slot `slot`
-    of obs (planes (M,2,A,4) or tiles (ceil(A/64),M,2,64,4)) in place and returns obs."""
+    of obs (planes (M,2,A,4), tiles (ceil(A/64),M,2,64,4) or per-agent lists (A,M,2,4)) in place and returns obs."""
     _need_gpu(px, "lane_fit")
     K, A = px.shape
     dev, ty = px.device, px.dtype
@@ -90,14 +93,15 @@ def lane_fit(px, py, obs, slot, sigma=None, degree=3, buffer=1.5):
     _check("py", py, (K, A), ty, dev)
     if sigma is not None:
         _check("sigma", sigma, (K, A), ty, dev)
-    tiled = obs.dim() == 5
-    M = obs.shape[1] if tiled else obs.shape[0]
-    _check("obs", obs, _obs_shape(A, M, tiled), ty, dev)
+    lflag, M, exp = obs_layout(obs, A)
+    if lflag == _lib.FLAG_OBS_SHARED:
+        raise ValueError("lane_fit writes per-agent slots: planes, tiles or per-agent lists")
+    _check("obs", obs, exp, ty, dev)
     lib = _lib.load()
     fn = lib.sccbf_lane_fit_f32 if ty == torch.float32 else lib.sccbf_lane_fit_f64
     with torch.cuda.device(dev):
         stream = torch.cuda.current_stream(dev).cuda_stream
         rc = fn(A, K, int(degree), _ptr(px), _ptr(py), _ptr(sigma), float(buffer), int(slot), M,
-                _lib.FLAG_OBS_TILED if tiled else 0, _ptr(obs), C.c_void_p(stream))
+                lflag, _ptr(obs), C.c_void_p(stream))
     _lib.check(rc)
     return obs

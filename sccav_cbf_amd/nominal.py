@@ -15,7 +15,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .batched import BatchedCBF, _ptr
+from .batched import BatchedCBF, _ptr, obs_layout
 
 
 def _check(name, t, shape, dtype, dev):
@@ -164,20 +164,9 @@ class ClosedLoop:
         if ty not in (torch.float32, torch.float64):
             raise ValueError("state must be float32 or float64")
         _check("state", state, (A, 4), ty, dev)
-        obs, flags = self.obs, 0
-        if not torch.is_tensor(obs) or obs.dim() not in (3, 4, 5):
-            raise ValueError("obs: expected planes (M,2,A,4), tiles (ceil(A/64),M,2,64,4) or a shared table (M,2,4)")
-        if obs.dim() == 5:
-            M = obs.shape[1]
-            flags |= _lib.FLAG_OBS_TILED
-            _check("obs", obs, ((A + 63) // 64, M, 2, 64, 4), ty, dev)
-        elif obs.dim() == 4:
-            M = obs.shape[0]
-            _check("obs", obs, (M, 2, A, 4), ty, dev)
-        else:
-            M = obs.shape[0]
-            flags |= _lib.FLAG_OBS_SHARED
-            _check("obs", obs, (M, 2, 4), ty, dev)
+        obs = self.obs
+        flags, M, exp = obs_layout(obs, A)
+        _check("obs", obs, exp, ty, dev)
         if not torch.is_tensor(self.obs_type) or self.obs_type.dim() not in (1, 2):
             raise ValueError("obs_type: expected uint8 (M,) or (M, A)")
         if self.obs_type.dim() == 2:

@@ -11,7 +11,8 @@ Two ways to get a rank its shard:
                 Monte-Carlo campaign and bench.py do)
   scatter       a batch assembled on one rank is cut into blocks and sent point to point, each block
                 once and at its own size; with align=64 the cuts fall on tile boundaries, so a rank's
-                slice of tiled obstacle slots (ceil(A/64), M, 2, 64, 4) is one contiguous block
+                slice of tiled obstacle slots (ceil(A/64), M, 2, 64, 4) is one contiguous block; so is
+                its slice of per-agent lists (A, M, 2, 4), wherever the cut falls
 """
 import torch
 import torch.distributed as dist
@@ -32,8 +33,10 @@ def shard_bounds(A, world, rank, align=1):
 
 def shard_batch(batch, world, rank):
     """Slice a full batch dict (state (A,4), u_ref (A,2), obs planes (M,2,A,4), tiles
-    (ceil(A/64),M,2,64,4) or shared (M,2,4), obs_type (M,) or (M,A)) down to the rank's block; tiled
-    obstacle slots are cut on tile boundaries."""
+    (ceil(A/64),M,2,64,4), per-agent lists (A,M,2,4) or shared (M,2,4), obs_type (M,) or (M,A)) down to the
+    rank's block; tiled obstacle slots are cut on tile boundaries."""
+    from .batched import obs_layout
+    from ._lib import FLAG_OBS_AGENT_MAJOR
     A = batch["state"].shape[0]
     obs, ty = batch["obs"], batch["obs_type"]
     lo, hi = shard_bounds(A, world, rank, align=TILE if obs.dim() == 5 else 1)
@@ -42,6 +45,8 @@ def shard_batch(batch, world, rank):
         out["obs"] = obs
     elif obs.dim() == 5:
         out["obs"] = obs[(lo + TILE - 1) // TILE:(hi + TILE - 1) // TILE].contiguous()   # (an empty block: lo = hi = A)
+    elif obs_layout(obs, A)[0] == FLAG_OBS_AGENT_MAJOR:
+        out["obs"] = obs[lo:hi].contiguous()
     else:
         out["obs"] = obs[:, :, lo:hi, :].contiguous()
     out["obs_type"] = ty if ty.dim() == 1 else ty[:, lo:hi].contiguous()
@@ -71,10 +76,13 @@ class ShardedCBF:
         communication; ranks differ by their seed only."""
         return make(A=agents_per_rank, seed=seed + self.rank)
 
-    def scatter(self, batch, A, M, dtype, device, src=0, per_agent_types=False, tiled=False):
+    def scatter(self, batch, A, M, dtype, device, src=0, per_agent_types=False, tiled=False, agent_major=False):
         """Distribute a batch that lives on `src` (other ranks pass None); returns this rank's
         shard on `device`.  Every block travels once, at its own size (no padding), point to point.
-        tiled: batch["obs"] is (ceil(A/64), M, 2, 64, 4) and the blocks are cut on tile boundaries."""
+        tiled: batch["obs"] is (ceil(A/64), M, 2, 64, 4) and the blocks are cut on tile boundaries.
+        agent_major: batch["obs"] is (A, M, 2, 4)."""
+        if tiled and agent_major:
+            raise ValueError("one layout: tiled or agent_major")
         world, rank = self.world, self.rank
         align = TILE if tiled else 1
         cdev = torch.device("cpu") if _is_gloo(self.group) else device
@@ -83,7 +91,8 @@ class ShardedCBF:
             lo, hi = shard_bounds(A, world, r, align)
             n = hi - lo
             shapes = [("state", (n, 4), dtype), ("u_ref", (n, 2), dtype),
-                      ("obs", ((n + TILE - 1) // TILE, M, 2, TILE, 4) if tiled else (M, 2, n, 4), dtype)]
+                      ("obs", ((n + TILE - 1) // TILE, M, 2, TILE, 4) if tiled else
+                       ((n, M, 2, 4) if agent_major else (M, 2, n, 4)), dtype)]
             if per_agent_types:
                 shapes.append(("obs_type", (M, n), torch.uint8))
             return lo, hi, shapes
@@ -91,6 +100,8 @@ class ShardedCBF:
         def cut(name, lo, hi):
             t = batch[name]
             if name == "obs":
+                if agent_major:
+                    return t[lo:hi]
                 return t[(lo + TILE - 1) // TILE:(hi + TILE - 1) // TILE] if tiled else t[:, :, lo:hi, :]
             if name == "obs_type":
                 return t[:, lo:hi]

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Launch time of the filter over the number of rows per QP, for every model:
-65536 agents (fp32, tiled slots), M = 16, 64, 257, 1024; the library picks the kernel (4 lanes per QP up
+65536 agents (fp32; slots in 64-agent tiles, or --layout agents / planes), M = 16, 64, 257, 1024; the library picks the kernel (4 lanes per QP up
 to 64 rows, 16 up to 256, one wavefront per QP beyond).
 
-    python tools/bench_rows.py [--agents 65536] [--rows 16,64,257,1024]
+    python tools/bench_rows.py [--agents 65536] [--rows 16,64,257,1024] [--layout agents]
 """
 import argparse
 import os
@@ -14,7 +14,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sccav_cbf_amd import scenarios  # noqa: E402
-from sccav_cbf_amd.batched import BatchedCBF, planes_to_tiled  # noqa: E402
+from sccav_cbf_amd.batched import BatchedCBF, planes_to_agents, planes_to_tiled  # noqa: E402
 from sccav_cbf_amd._lib import OBS_LANE as LANE  # noqa: E402
 
 
@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--rows", default="16,64,257,1024")
     ap.add_argument("--lanes", default="0", help="lanes_per_qp values to try (0: the library's choice)")
     ap.add_argument("--models", default="dbm,kbm,dum,sadbm")
+    ap.add_argument("--layout", default="tiles", choices=("tiles", "agents", "planes"),
+                    help="obstacle layout: 64-agent tiles, per-agent lists (A,M,2,4) or planes (M,2,A,4)")
     ap.add_argument("--sorted", action="store_true", help="slots grouped by kind instead of 8 + 8 repeated")
     ap.add_argument("--branches", type=int, default=1,
                     help="parallel branches of the captured walk: the launches are independent batches")
@@ -54,7 +56,8 @@ def main():
                 obs = obs[order].contiguous()
             ring.append(dict(state=torch.from_numpy(np.roll(base["state"], 64 * 331 * (b + 1), axis=0)).float().to(dev),
                              u_ref=torch.from_numpy(np.roll(base["u_ref"], 64 * 331 * (b + 1), axis=0)).float().to(dev),
-                             obs=planes_to_tiled(obs)))
+                             obs={"tiles": planes_to_tiled, "agents": planes_to_agents,
+                                  "planes": lambda o: o}[args.layout](obs)))
             del obs
         ty = np.tile(base["obs_type"], reps)[:M].copy()
         ty = torch.from_numpy(np.sort(ty, kind="stable") if args.sorted else ty).to(dev)
