@@ -250,6 +250,31 @@ def large_batch(flt, device, layout, slots, agents=1 << 20, n=3, reps=200, graph
             "launches": reps * n, "launch": "one at a time (serial hipGraph)" if graph else "eager"}
 
 
+def long_lists_section(device):
+    """Lists of 128, 257 and 1024 slots per agent at 65536 agents (fp32, DBM), one launch at a time: from per-agent
+    lists (SCCBF_FLAG_OBS_AGENT_MAJOR), the layout the kernels for long lists stream fastest from, and from the
+    64-agent tiles of the headline."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from bench_rows import rows_ring, time_rows
+    from sccav_cbf_amd import scenarios
+    base = scenarios.prepared(scenarios.config4(A=AGENTS, nominal="uniform", seed=3))
+    flt = _filter()
+    out = {}
+    for M in (128, 257, 1024):
+        row = {}
+        for layout in ("agents", "tiles"):
+            ring, ty = rows_ring(base, M, AGENTS, device, layout)
+            us, frac, st = time_rows(flt, ring, ty, AGENTS, M)
+            row[layout] = {"us_per_launch": us, "frac": frac, "solves_per_s": AGENTS / (us * 1e-6),
+                           "infeasible_fraction": float((st == 1).float().mean())}
+            del ring
+            torch.cuda.empty_cache()
+        out["rows_%d" % M] = row
+    out["note"] = ("65536 agents, fp32, prepared ellipse / cone slots repeated at growing distance; frac = algorithmic bytes "
+                   "(32 M + 36 per agent) / launch time / 8 TB/s; agents = obs as (A, M, 2, 4), tiles = (A/64, M, 2, 64, 4)")
+    return out
+
+
 def variants_section(ring, device, stream):
     """Lanes per QP at C4: 64 = the one-wavefront-per-QP variant, 0 = the library's choice (4 at this size)."""
     out = {}
@@ -829,6 +854,11 @@ def extras(args, out, reg, device, stream):
         out["fp64"] = {"c4": cf["c4"]["f64"], "c5": cf["c5"]["f64"], "c2": cf["c2"]}
     except Exception as e:
         out["configs"] = {"error": repr(e)}
+    try:
+        torch.cuda.empty_cache()
+        out["long_lists"] = long_lists_section(device)
+    except Exception as e:
+        out["long_lists"] = {"error": repr(e)}
     if not args.no_large:
         try:
             torch.cuda.empty_cache()

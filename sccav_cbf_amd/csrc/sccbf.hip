@@ -143,9 +143,12 @@ int fill_args(const sccbf_params* sp, int64_t A, int32_t M, KArgs<T>& k)
 // 4 lanes from 32768 QPs up to 1M, 8 around 8192-16384, 16 below; with 32 ... 128 rows and 65536 QPs
 // 8 lanes; from there on the kernels that keep the rows in LDS only are faster than 16 lanes x 16
 // registers: 98 against 116 us at 200 rows, 116 against 130 at 256)
-int auto_lanes(int64_t A, int M)
+// From per-agent lists 16 lanes read runs of 16 consecutive slots of an agent: 65 ... 128 rows, 65536 QPs:
+// 44 against 57 us at 96 rows, 53 against 63 at 128 (from tiles 8 lanes: 50 and 59).
+int auto_lanes(int64_t A, int M, uint32_t flags)
 {
     if (M > 128) return 64;  // rows in LDS only; wave_lanes() then picks the group
+    if ((flags & SCCBF_FLAG_OBS_AGENT_MAJOR) && M > 64) return 16;
     int g;
     if (A >= (1 << 15)) g = M <= 16 ? 4 : 8;
     else if (A >= (1 << 13)) g = 8;
@@ -273,7 +276,7 @@ int dispatch(const sccbf_params* sp, KArgs<T>& k, void* stream)
         return launched_();
     }
     int lanes = sp->lanes_per_qp;
-    if (lanes == 0) lanes = auto_lanes(k.A, k.M);
+    if (lanes == 0) lanes = auto_lanes(k.A, k.M, k.flags);
     if (lanes == 64 && sp->lanes_per_qp == 0) lanes = wave_lanes<T>(k.M);
     switch (lanes) {
     case 1: return launch_group_rpl<T, QP_ONLY, 1>(k, s);
@@ -331,6 +334,7 @@ int dispatch_ext(const sccbf_params* sp, const KArgs<T>& k, const XArgs<T>& x, v
     int lanes = sp->lanes_per_qp;
     if (lanes == 0) {  // as for the bicycle models (auto_lanes)
         if (k.M > 128) lanes = wave_lanes<T>(k.M);
+        else if ((k.flags & SCCBF_FLAG_OBS_AGENT_MAJOR) && k.M > 64) lanes = 16;
         else if (k.A >= (1 << 13)) lanes = k.M <= 16 ? 4 : 8;
         else lanes = 16;
     }
@@ -769,7 +773,7 @@ int batches_launch(const sccbf_params* sp, int32_t K, int32_t M, int64_t a_max, 
     const double total = (double)a_max * K;
     const int64_t a_all = total > 2147483647.0 ? 0x7fffffffLL : (int64_t)total;
     int lanes = sp->lanes_per_qp;
-    if (lanes == 0) lanes = auto_lanes(a_all, M);
+    if (lanes == 0) lanes = auto_lanes(a_all, M, sp->flags);
     if (lanes == 64 && sp->lanes_per_qp == 0) lanes = wave_lanes<T>(M);
     const bool nt = (sp->flags & SCCBF_FLAG_OBS_STREAMED) || total * M * 8 * sizeof(T) >= kNtBytes;
     switch (lanes) {

@@ -76,6 +76,12 @@ def test_bench_line_has_the_contracts_fields():
         _step_line(sh["twenty_steps_per_launch"])
         _step_line(sh["one_launch_per_step"])
     assert 0.5 < d["roofline_large_batch"]["frac"] < 1.0
+    # long obstacle lists, from per-agent lists and from tiles
+    for M in (128, 257, 1024):
+        for layout in ("agents", "tiles"):
+            row = d["long_lists"]["rows_%d" % M][layout]
+            assert 0.35 < row["frac"] < 1.0 and abs(row["solves_per_s"] * row["us_per_launch"] * 1e-6 - 65536) < 1.0
+        assert d["long_lists"]["rows_%d" % M]["agents"]["frac"] > 0.5
 
 
 def test_a_long_region_and_one_launch_per_step():

@@ -18,6 +18,71 @@ from sccav_cbf_amd.batched import BatchedCBF, planes_to_agents, planes_to_tiled 
 from sccav_cbf_amd._lib import OBS_LANE as LANE  # noqa: E402
 
 
+def rows_ring(base, M, A, dev, layout="tiles", by_kind=False, nbytes=600_000_000):
+    """Distinct batches of A agents x M slots (more than twice the Infinity Cache together) made from the 16-slot
+    batch `base` (scenarios.prepared(config4)): copy k of an obstacle stands 10 k .. 10 k + 10 m farther from the
+    agent along the line of sight (lane slots stay as they are), so the feasible share of the batch stays that
+    of 16 rows.  Returns (ring of dicts state / u_ref / obs, obs_type)."""
+    reps = -(-M // 16)
+    ring = []
+    nring = max(2, -(-nbytes // (A * (32 * M + 36))))
+    kinds = np.tile(base["obs_type"], reps)[:M]
+    for b in range(nring):
+        sh = 64 * 331 * (b + 1)
+        obs = torch.from_numpy(np.roll(base["obs"], sh, axis=2)).float().to(dev)
+        obs = obs.repeat(reps, 1, 1, 1)[:M].contiguous()
+        ego = torch.from_numpy(np.roll(base["state"], sh, axis=0)[:, 0:2]).float().to(dev)
+        is_lane = torch.from_numpy(kinds == LANE).to(dev)
+        los = obs[:, 0, :, 0:2] - ego[None]
+        los = los / los.norm(dim=2, keepdim=True).clamp_min(1e-3)
+        far = (torch.arange(M, device=dev) // 16).float()[:, None, None] * 10.0
+        far = far + 10.0 * torch.rand((M, 1, 1), device=dev) * (far > 0)
+        obs[:, 0, :, 0:2] += torch.where(is_lane[:, None, None], torch.zeros_like(los), los * far)
+        if by_kind:
+            order = torch.from_numpy(np.argsort(kinds, kind="stable")).to(dev)
+            obs = obs[order].contiguous()
+        ring.append(dict(state=torch.from_numpy(np.roll(base["state"], sh, axis=0)).float().to(dev),
+                         u_ref=torch.from_numpy(np.roll(base["u_ref"], sh, axis=0)).float().to(dev),
+                         obs={"tiles": planes_to_tiled, "agents": planes_to_agents,
+                              "planes": lambda o: o}[layout](obs)))
+        del obs
+    ty = torch.from_numpy(np.sort(kinds, kind="stable") if by_kind else kinds.copy()).to(dev)
+    return ring, ty
+
+
+def time_rows(f, ring, ty, A, M, branches=1, **kw):
+    """us per launch of filter f over the ring, one launch at a time from a captured walk (about ten launches per
+    replay), and the status of the first batch."""
+    from sccav_cbf_amd.batched import capture_independent
+    dev = ty.device
+    nring = len(ring)
+    abytes = A * (4 * (4 + 2 + 8 * M + 2) + 4)
+    inner = max(1, 10 // nring)   # about 10 launches per captured walk: a replay's own start is a small share
+    outs = [(torch.empty((A, 2), device=dev), torch.empty((A,), dtype=torch.int32, device=dev))
+            for _ in ring * inner]   # launches may overlap
+    steps = [(lambda b=b, o=o: f.solve(b["state"], b["u_ref"], b["obs"], ty, u_out=o[0], status=o[1], **kw))
+             for b, o in zip(ring * inner, outs)]
+    for _ in range(3):
+        for st in steps:
+            st()
+    torch.cuda.synchronize()
+    cs = torch.cuda.Stream(dev)
+    with torch.cuda.stream(cs):
+        g = capture_independent(steps, branches)
+    n = max(3, min(100, int(4e9 // abytes)))
+    for _ in range(n):
+        g.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / (nring * inner * n)
+    return us, abytes / (us * 1e-6) / 8e12, outs[0][1]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--agents", type=int, default=65536)
@@ -35,72 +100,18 @@ def main():
     base = scenarios.prepared(scenarios.config4(A=A, nominal="uniform", seed=3))
     torch.manual_seed(1)
     for M in [int(m) for m in args.rows.split(",")]:
-        reps = -(-M // 16)
-        ring = []
-        nring = max(2, -(-600_000_000 // (A * (32 * M + 36))))   # distinct batches: more than twice the Infinity Cache
-        for b in range(nring):
-            sh = 64 * 331 * (b + 1)
-            obs = torch.from_numpy(np.roll(base["obs"], sh, axis=2)).float().to(dev)
-            obs = obs.repeat(reps, 1, 1, 1)[:M].contiguous()
-            # copy k of an obstacle stands 10 k .. 10 k + 10 m farther from the agent along the line of sight
-            # (lane slots stay as they are), so the feasible share of the batch stays that of 16 rows
-            ego = torch.from_numpy(np.roll(base["state"], sh, axis=0)[:, 0:2]).float().to(dev)
-            is_lane = torch.from_numpy(np.tile(base["obs_type"], reps)[:M] == LANE).to(dev)
-            los = obs[:, 0, :, 0:2] - ego[None]
-            los = los / los.norm(dim=2, keepdim=True).clamp_min(1e-3)
-            far = (torch.arange(M, device=dev) // 16).float()[:, None, None] * 10.0
-            far = far + 10.0 * torch.rand((M, 1, 1), device=dev) * (far > 0)
-            obs[:, 0, :, 0:2] += torch.where(is_lane[:, None, None], torch.zeros_like(los), los * far)
-            if args.sorted:
-                order = torch.from_numpy(np.argsort(np.tile(base["obs_type"], reps)[:M], kind="stable")).to(dev)
-                obs = obs[order].contiguous()
-            ring.append(dict(state=torch.from_numpy(np.roll(base["state"], 64 * 331 * (b + 1), axis=0)).float().to(dev),
-                             u_ref=torch.from_numpy(np.roll(base["u_ref"], 64 * 331 * (b + 1), axis=0)).float().to(dev),
-                             obs={"tiles": planes_to_tiled, "agents": planes_to_agents,
-                                  "planes": lambda o: o}[args.layout](obs)))
-            del obs
-        ty = np.tile(base["obs_type"], reps)[:M].copy()
-        ty = torch.from_numpy(np.sort(ty, kind="stable") if args.sorted else ty).to(dev)
-        u = torch.empty((A, 2), device=dev)
-        st = torch.empty((A,), dtype=torch.int32, device=dev)
+        ring, ty = rows_ring(base, M, A, dev, args.layout, args.sorted)
         slip = torch.zeros((A, 2), device=dev)
-        abytes = A * (4 * (4 + 2 + 8 * M + 2) + 4)
         for name, lanes in [(n, int(l)) for n in args.models.split(",") for l in args.lanes.split(",")]:
             f = BatchedCBF(alpha=1.0, R=np.diag([0.5, 0.5]), dynamics=name, streamed_obs=True, lanes_per_qp=lanes)
             kw = dict(slip=slip, dt=0.1) if name == "sadbm" else {}
-
-            inner = max(1, 10 // nring)   # about 10 launches per captured walk: a replay's own start is a small share
-
-            def walk():
-                for b in ring * inner:
-                    f.solve(b["state"], b["u_ref"], b["obs"], ty, u_out=u, status=st, **kw)
             try:
-                for _ in range(3):
-                    walk()
+                us, frac, st = time_rows(f, ring, ty, A, M, args.branches, **kw)
             except Exception as exc:    # a variant that cannot hold this many rows
                 print("M %4d %-6s lanes %2d: %s" % (M, name, lanes, str(exc)[:60]), flush=True)
                 continue
-            torch.cuda.synchronize()
-            from sccav_cbf_amd.batched import capture_independent
-            outs = [(torch.empty_like(u), torch.empty_like(st)) for _ in ring * inner]   # launches may overlap
-            steps = [(lambda b=b, o=o: f.solve(b["state"], b["u_ref"], b["obs"], ty, u_out=o[0], status=o[1], **kw))
-                     for b, o in zip(ring * inner, outs)]
-            cs = torch.cuda.Stream(dev)
-            with torch.cuda.stream(cs):
-                g = capture_independent(steps, args.branches)
-            n = max(3, min(100, int(4e9 // abytes)))
-            for _ in range(n):
-                g.replay()
-            torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(n):
-                g.replay()
-            e1.record()
-            torch.cuda.synchronize()
-            us = e0.elapsed_time(e1) * 1e3 / (nring * inner * n)
             print("M %4d %-6s lanes %2d %9.2f us per launch  %.3f of 8 TB/s  infeasible %.2f" %
-                  (M, name, lanes, us, abytes / (us * 1e-6) / 8e12, float((outs[0][1] == 1).float().mean())), flush=True)
+                  (M, name, lanes, us, frac, float((st == 1).float().mean())), flush=True)
         del ring
         torch.cuda.empty_cache()
 
