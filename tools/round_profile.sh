@@ -3,6 +3,7 @@
 # one launch per step and of the 2^20-agent launch, and the HBM traffic counter passes (one rocprofv3 --pmc run per
 # counter group) of the headline's launch.
 set -e
+: > gpurun_out/r3_rows_sweep.txt
 timeout -k 10 500 python -u bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r3_bench_steps20.json 2> gpurun_out/r3_bench_steps20.err
 bash tools/prof_kernel.sh r3_stats > gpurun_out/r3_stats.txt 2>&1
 bash tools/prof_kernel.sh r3_stats_single --fuse 1 --steps 2000 --warmup 200 > gpurun_out/r3_stats_single.txt 2>&1
@@ -15,3 +16,20 @@ bash tools/prof_pmc.sh r3_large_fsize "FETCH_SIZE" --large-only --steps 5 > gpur
 bash tools/prof_pmc.sh r3_large_write "WRITE_SIZE" --large-only --steps 5 > gpurun_out/r3_large_write.txt 2>&1
 python3 tools/traffic_json.py gpurun_out/r3_large_fsize gpurun_out/r3_large_write gpurun_out/r3_traffic_large.json 1048576 "k_group<" "bench.py --large-only --steps 5" > gpurun_out/r3_traffic_large.txt 2>&1
 timeout -k 10 500 python -u bench.py > gpurun_out/r3_bench.json 2> gpurun_out/r3_bench.err
+# fp64: kernel stats and HBM counters of the fused launch (twenty 65536 x 16 batches per sccbf_solve_batches_f64 launch)
+( cd /tmp && export TMPDIR=/tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/r3_f64_stats -- python3 $GRAFT_REPO_ROOT/tools/bench_batches.py --dtype f64 --ks 20 --reps 200 > $GRAFT_REPO_ROOT/gpurun_out/r3_f64_stats.log 2>&1 )
+cp $(find gpurun_out/r3_f64_stats -name "*kernel_stats.csv" | head -1) gpurun_out/r3_f64_kernel_stats.csv
+: > gpurun_out/r3_f64_pmc.txt
+for CTRS in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY"; do
+  rm -rf gpurun_out/r3_f64_pmc.d
+  ( cd /tmp && export TMPDIR=/tmp && timeout -s KILL 160 rocprofv3 --pmc $CTRS --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/r3_f64_pmc.d -- python3 $GRAFT_REPO_ROOT/tools/bench_batches.py --dtype f64 --ks 20 --reps 20 > $GRAFT_REPO_ROOT/gpurun_out/r3_f64_pmc.log 2>&1 )
+  python3 tools/pmc_summary.py gpurun_out/r3_f64_pmc.d >> gpurun_out/r3_f64_pmc.txt
+done
+rm -rf gpurun_out/r3_f64_pmc.d
+# long obstacle lists: launch times of every model from per-agent lists and from tiles, then the counters of the three kernel families
+for L in agents tiles; do
+  echo "== layout $L" >> gpurun_out/r3_rows_sweep.txt
+  timeout -k 10 500 python -u tools/bench_rows.py --layout $L --rows 16,64,128,129,200,257,512,1024 2>&1 | grep "^M" >> gpurun_out/r3_rows_sweep.txt
+done
+LAYOUT=agents bash tools/prof_rows_pmc.sh 128 257 1024
+LAYOUT=tiles bash tools/prof_rows_pmc.sh 128 257 1024
