@@ -14,7 +14,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import oracle as orc  # noqa: E402
-from sccav_cbf_amd.batched import BatchedCBF, planes_to_tiled  # noqa: E402
+from sccav_cbf_amd.batched import BatchedCBF, planes_to_agents, planes_to_tiled  # noqa: E402
 from tests import parity  # noqa: E402
 from tests.test_gpu_parity import _near_feasibility_boundary  # noqa: E402
 
@@ -108,14 +108,33 @@ def main():
     ap.add_argument("--special", type=float, default=0.0,
                     help="share of the agents given special values (headings on the axes and next to them, cones at the "
                          "agent's own velocity and with the agent on their rim); 0 keeps the random stream of earlier runs")
+    ap.add_argument("--extra", type=float, default=0.0,
+                    help="share of the slots replaced by lanes of degree 4 ... 6 (kind 8); with it the layout is drawn "
+                         "from planes / tiles / per-agent lists and 513 rows join the row counts.  Drawn from a stream "
+                         "of its own: 0 keeps the random stream of earlier runs")
     args = ap.parse_args()
     rng = np.random.default_rng(args.seed)
+    xrng = np.random.default_rng([args.seed, 7])
     orc.build()
     misses, total64, total32, st_mism32, worst32 = 0, 0, 0, 0, 0.0
     for case in range(args.cases):
         M = int(rng.choice([1, 2, 3, 4, 7, 8, 12, 16, 17, 24, 32, 48, 64, 100, 257]))
+        if args.extra > 0 and xrng.uniform() < 0.03:
+            M = 513
         A = (args.agents if M <= 64 else 128) + int(rng.integers(0, 70))
         state, u_ref, obs, kinds = random_case(rng, A, M, args.special)
+        layout = -1
+        if args.extra > 0:
+            layout = int(xrng.integers(0, 3))       # planes, tiles, per-agent lists
+            for m in range(M):
+                if xrng.uniform() < args.extra:     # a lane boundary of degree 4 ... 6: c0 ... c6, buffer
+                    deg = int(xrng.integers(4, 7))
+                    c = np.stack([np.full(A, 15.0 + xrng.choice([-1.0, 1.0]) * 12.0), xrng.uniform(-0.05, 0.05, A),
+                                  xrng.uniform(-1e-3, 1e-3, A), xrng.uniform(-1e-5, 1e-5, A), xrng.uniform(-1e-7, 1e-7, A),
+                                  xrng.uniform(-1e-9, 1e-9, A), xrng.uniform(-1e-11, 1e-11, A), np.full(A, 1.5)], axis=1)
+                    c[:, deg + 1:7] = 0.0
+                    obs[m] = c.reshape(A, 2, 4).transpose(1, 0, 2)
+                    kinds[m] = 8
         q = rng.normal(size=(2, 2))
         R = q @ q.T + 0.3 * np.eye(2)
         alpha = float(rng.choice([0.3, 1.0, 4.0]))
@@ -125,6 +144,8 @@ def main():
         tiled = bool(rng.integers(0, 2))
         lanes = int(rng.choice([0, 1, 2, 4, 8, 16, 32, 64]))
         if lanes not in (0, 16, 32, 64) and M > 16 * lanes:
+            lanes = 0
+        if lanes == 16 and M > 400:     # sixteen tables of so many fp64 rows do not fit a CU's LDS
             lanes = 0
         if dyn in ("dum", "sadbm"):     # these models run with 4 lanes per QP (up to 64 rows), 8 (128), 16, 32 or 64
             lanes = lanes if lanes in (0, 16, 32, 64) or (lanes == 4 and M <= 64) or (lanes == 8 and M <= 128) else 0
@@ -179,13 +200,17 @@ def main():
         sens = np.abs(ro - ro32)
         for _ in range(7):
             sens = np.maximum(sens, np.abs(rows_of(jitter) - ro32))
-        tag = "case %d M=%d A=%d %s slip=%d per_agent=%d tiled=%d lanes=%d alpha=%g" % (
-            case, M, A, dyn, slip, per_agent, tiled, lanes, alpha)
+        if layout >= 0:
+            tiled = layout == 1
+        tag = "case %d M=%d A=%d %s slip=%d per_agent=%d tiled=%d lists=%d lanes=%d alpha=%g" % (
+            case, M, A, dyn, slip, per_agent, tiled, layout == 2, lanes, alpha)
         for dtype in (torch.float64, torch.float32):
             f = BatchedCBF(alpha=alpha, R=R, dynamics=dyn, slip_io=slip and dyn in ("dbm", "kbm"), lanes_per_qp=lanes)
             tobs = torch.from_numpy(obs).to(DEV).to(dtype)
             if tiled:
                 tobs = planes_to_tiled(tobs)
+            elif layout == 2:
+                tobs = planes_to_agents(tobs)
             kw = {}
             if dyn == "sadbm":
                 kw = dict(slip=torch.from_numpy(sa_slip).to(DEV).to(dtype), dt=sa_dt, cone_beta_state=cone_beta)

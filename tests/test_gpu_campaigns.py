@@ -12,7 +12,9 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "campaigns")
 
 
-@pytest.mark.parametrize("name,cases,extra", [("fuzz_parity", 150, []), ("fuzz_nominal", 60, []),
+@pytest.mark.parametrize("name,cases,extra", [("fuzz_parity", 150, []),
+                                              ("fuzz_parity", 150, ["--extra", "0.1", "--agents", "256"]),
+                                              ("fuzz_nominal", 60, []),
                                               ("fuzz_rollout", 60, []), ("fuzz_rollout", 60, ["--dtype", "f32"]),
                                               ("fuzz_ingest", 40, [])])
 def test_campaign(oracle, monkeypatch, name, cases, extra):
