@@ -77,17 +77,28 @@ def _worker(rank, world, port, A, per_agent, tiled, ret):
                 ty[::3, ::5] = 255
                 w["obs_type"] = np.ascontiguousarray(ty)
             batch = {k: torch.from_numpy(v) for k, v in w.items()}
-        from sccav_cbf_amd.batched import planes_to_tiled
+        from sccav_cbf_amd.batched import planes_to_agents, planes_to_tiled
+        lists = tiled == "lists"       # per-agent lists (A, M, 2, 4): cut anywhere, a rank's share is one block
+        tiled = tiled is True
         planes = None
         if rank == 0:
             planes = batch["obs"]
             if tiled:
                 batch["obs"] = planes_to_tiled(planes)
+            elif lists:
+                batch["obs"] = planes_to_agents(planes)
         sh = ShardedCBF(solve)
         align = 64 if tiled else 1
-        shard = sh.scatter(batch, A, M, torch.float64, torch.device("cpu"), per_agent_types=per_agent, tiled=tiled)
+        shard = sh.scatter(batch, A, M, torch.float64, torch.device("cpu"), per_agent_types=per_agent, tiled=tiled,
+                           agent_major=lists)
         lo, hi = shard_bounds(A, world, rank, align)
         assert shard["state"].shape == (hi - lo, 4)
+        if lists:
+            assert shard["obs"].shape == (hi - lo, M, 2, 4) and shard["obs"].is_contiguous()
+            if rank == 0:
+                from sccav_cbf_amd.sharded import shard_batch
+                assert torch.equal(shard_batch(batch, world, rank)["obs"], shard["obs"])
+            shard["obs"] = shard["obs"].permute(1, 2, 0, 3).contiguous()
         if tiled:    # a rank's tiles are one contiguous block of the batch; back to planes for the oracle
             assert shard["obs"].shape == ((hi - lo + 63) // 64, M, 2, 64, 4) and shard["obs"].is_contiguous()
             shard["obs"] = shard["obs"].permute(1, 2, 0, 3, 4).reshape(M, 2, -1, 4)[:, :, :hi - lo].contiguous()
@@ -105,7 +116,8 @@ def _worker(rank, world, port, A, per_agent, tiled, ret):
 
 
 @pytest.mark.parametrize("A,per_agent,tiled", [(1000, False, False), (1001, True, False), (1001, False, True),
-                                              (130, True, True), (40, False, True)])
+                                              (130, True, True), (40, False, True), (1001, False, "lists"),
+                                              (131, True, "lists")])
 def test_two_rank_gloo_scatter_solve_gather(A, per_agent, tiled):
     from oracle import oracle as orc
     orc.build()
