@@ -11,7 +11,7 @@ inputs from HBM.  The steps are independent batches (a Monte-Carlo sweep: every 
 outputs), and the timed region hands them to the library twenty at a time: ONE launch of
 sccbf_solve_batches_f32 over twenty batch records (the answers of twenty sccbf_solve_f32 launches, bit for bit).
 --scaling weak (default): every rank owns a full ring of 65536-agent batches; strong: ONE 65536-agent batch per
-step, every rank solves its contiguous block of 65536 / N agents (BASELINE's configuration 4 as stated).  Either
+step, every rank solves its contiguous block of 65536 / N agents (the 65536-agent x 16-row configuration as the baseline states it).  Either
 way the solve has no collective.  Rank 0 prints ONE JSON line.
 Order: untimed clock ramp (--ramp-ms of work, an idle GPU is slow for its first milliseconds), W untimed
 warm-up steps, barrier, exactly K timed steps, barrier.

@@ -348,12 +348,16 @@ __device__ inline bool slot_partials_(int type, const T o_in[8], const Ego<T>& e
     T o[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) o[i] = o_in[i];
-    if (type == SCCBF_OBS_ELLIPSE_BOX) {         // the obstacle the box stands for: the ellipse as written,
-        box_ellipse_(o_in, o);
-        type = SCCBF_OBS_ELLIPSE;
-    } else if (type == SCCBF_OBS_CONE_BOX) {     // the cone with its velocity (speed, 0) resolved
-        box_cone_prep_(o_in, o);
-        type = SCCBF_OBS_CONE_PREP;
+    // A wavefront without a box among its slots skips the conversion as a whole (a scalar branch): the lanes of a
+    // masked branch would pay a register copy per slot value for the join with the converted ones.
+    if (__any(type == SCCBF_OBS_ELLIPSE_BOX || type == SCCBF_OBS_CONE_BOX)) {
+        if (type == SCCBF_OBS_ELLIPSE_BOX) {         // the obstacle the box stands for: the ellipse as written,
+            box_ellipse_(o_in, o);
+            type = SCCBF_OBS_ELLIPSE;
+        } else if (type == SCCBF_OBS_CONE_BOX) {     // the cone with its velocity (speed, 0) resolved
+            box_cone_prep_(o_in, o);
+            type = SCCBF_OBS_CONE_PREP;
+        }
     }
     switch (type) {
     case SCCBF_OBS_ELLIPSE: ellipse_(e.x, e.y, o, d); return true;

@@ -1,4 +1,4 @@
-# Everything the committed round-3 profiles come from (results under gpurun_out/r3_*): the bench line of the driver's
+# Everything the committed profiles of the current library come from (results under gpurun_out/r3_*): the bench line of the driver's
 # command and of the default command, rocprofv3 kernel stats of the headline's launches (twenty batches per launch), of
 # one launch per step and of the 2^20-agent launch, and the HBM traffic counter passes (one rocprofv3 --pmc run per
 # counter group) of the headline's launch.
