@@ -204,12 +204,13 @@ template <typename T, int G> struct WaveShape {
 
 template <typename T> size_t wave_lds(int M, int qpb, int G) { return wave_lds_bytes<T>(M, qpb, G); }
 
-// lanes per QP when the library chooses (measured at 65536 agents, fp32, 129 ... 1024 rows): the narrowest
-// group of which four workgroups still fit a CU (16 lanes up to 208 fp32 rows, 32 up to 416), else a
-// wavefront per QP, whose workgroups have twice the wavefronts for the same tables
+// lanes per QP when the library chooses (measured at 65536 agents, fp32, 129 ... 1024 rows, both layouts): 16 lanes
+// while five workgroups fit a CU (the kernels run five wavefronts per SIMD; up to 160 fp32 rows: 69 against 74 us at
+// 160 rows, 95 against 89 at 200), 32 while four do (up to 416: 147 against 164 us at 350 rows), else a wavefront per
+// QP, whose workgroups have twice the wavefronts for the same tables
 template <typename T> int wave_lanes(int M)
 {
-    if (wave_lds<T>(M, WaveShape<T, 16>::kQpb, 16) * 4 <= kLdsPerCu) return 16;
+    if (wave_lds<T>(M, WaveShape<T, 16>::kQpb, 16) * 5 <= kLdsPerCu) return 16;
     if (wave_lds<T>(M, WaveShape<T, 32>::kQpb, 32) * 4 <= kLdsPerCu) return 32;
     return 64;
 }

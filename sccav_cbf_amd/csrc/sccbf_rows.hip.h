@@ -5,6 +5,10 @@
 
 namespace {
 
+// Inside a block whose condition is uniform over the wavefront: an empty statement the compiler may not hoist, so the block
+// stays behind its scalar branch instead of being evaluated by everybody and selected away afterwards.
+__device__ inline void keep_branch_() { __asm__ volatile(""); }
+
 // --------------------------------------------------------------------- barriers
 template <typename T> struct Partials {
     T h, hx, hy, hth, hv, ht;
@@ -96,7 +100,10 @@ __device__ inline void cone_(T x, T y, T th, T v, T cth, T sth, const T o[8], T 
     T so, co;
     sincos_(o[2] + beta, &so, &co);
     T c = cth, sn = sth;
-    if (beta != T(0)) sincos_(th + beta, &sn, &c);
+    if (__any(beta != T(0))) {  // scalar branch: without it the sine and cosine are evaluated for every cone and then discarded
+        keep_branch_();
+        if (beta != T(0)) sincos_(th + beta, &sn, &c);
+    }
     cone_core_(x - o[0], y - o[1], v * cth, v * sth, o[3] * co, o[3] * so, o[4], c, sn, eps, r);
 }
 
@@ -108,7 +115,10 @@ __device__ inline void cone_prep_(T x, T y, T th, T v, T cth, T sth, const T o[8
 {
     T beta = o[5];
     T c = cth, sn = sth;
-    if (beta != T(0)) sincos_(th + beta, &sn, &c);
+    if (__any(beta != T(0))) {  // scalar branch, as in cone_
+        keep_branch_();
+        if (beta != T(0)) sincos_(th + beta, &sn, &c);
+    }
     cone_core_(x - o[0], y - o[1], v * cth, v * sth, o[2], o[3], o[4], c, sn, eps, r);
 }
 

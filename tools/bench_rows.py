@@ -70,9 +70,12 @@ def time_rows(f, ring, ty, A, M, branches=1, **kw):
     with torch.cuda.stream(cs):
         g = capture_independent(steps, branches)
     n = max(3, min(100, int(4e9 // abytes)))
-    for _ in range(n):
-        g.replay()
-    torch.cuda.synchronize()
+    import time
+    t0 = time.perf_counter()       # the GPU needs tens of milliseconds of work to reach its clocks
+    while time.perf_counter() - t0 < 0.08:
+        for _ in range(n):
+            g.replay()
+        torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(n):
