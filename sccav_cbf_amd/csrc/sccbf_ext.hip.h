@@ -24,22 +24,26 @@ __device__ inline void ext_slot_row_(int type, T (&o)[8], const Ego<T>& e, const
 {
     Partials<T> d;
     T hb = T(0);
-    if (type == SCCBF_OBS_ELLIPSE_BOX || type == SCCBF_OBS_CONE_BOX) {
-        // the obstacle the box stands for: the ellipse as written, the cone with its velocity (speed, 0) resolved
-        // as the bicycle models take it, or as written (theta_o = 0) when it has to follow the agent's beta
-        T q[8];
-        if (type == SCCBF_OBS_ELLIPSE_BOX) {
-            box_ellipse_(o, q);
-            type = SCCBF_OBS_ELLIPSE;
-        } else if (cone_beta_state) {
-            box_cone_(o, q);
-            type = SCCBF_OBS_CONE;
-        } else {
-            box_cone_prep_(o, q);
-            type = SCCBF_OBS_CONE_PREP;
-        }
+    // a wavefront without a box among its slots skips the conversion as a whole (scalar branch, as in slot_partials_)
+    if (__any(type == SCCBF_OBS_ELLIPSE_BOX || type == SCCBF_OBS_CONE_BOX)) {
+        keep_branch_();
+        if (type == SCCBF_OBS_ELLIPSE_BOX || type == SCCBF_OBS_CONE_BOX) {
+            // the obstacle the box stands for: the ellipse as written, the cone with its velocity (speed, 0) resolved
+            // as the bicycle models take it, or as written (theta_o = 0) when it has to follow the agent's beta
+            T q[8];
+            if (type == SCCBF_OBS_ELLIPSE_BOX) {
+                box_ellipse_(o, q);
+                type = SCCBF_OBS_ELLIPSE;
+            } else if (cone_beta_state) {
+                box_cone_(o, q);
+                type = SCCBF_OBS_CONE;
+            } else {
+                box_cone_prep_(o, q);
+                type = SCCBF_OBS_CONE_PREP;
+            }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) o[i] = q[i];
+            for (int i = 0; i < 8; ++i) o[i] = q[i];
+        }
     }
     switch (type) {
     case SCCBF_OBS_ELLIPSE: ellipse_(e.x, e.y, o, d); break;

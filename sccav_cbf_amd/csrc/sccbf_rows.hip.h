@@ -361,6 +361,7 @@ __device__ inline bool slot_partials_(int type, const T o_in[8], const Ego<T>& e
     // A wavefront without a box among its slots skips the conversion as a whole (a scalar branch): the lanes of a
     // masked branch would pay a register copy per slot value for the join with the converted ones.
     if (__any(type == SCCBF_OBS_ELLIPSE_BOX || type == SCCBF_OBS_CONE_BOX)) {
+        keep_branch_();
         if (type == SCCBF_OBS_ELLIPSE_BOX) {         // the obstacle the box stands for: the ellipse as written,
             box_ellipse_(o_in, o);
             type = SCCBF_OBS_ELLIPSE;
