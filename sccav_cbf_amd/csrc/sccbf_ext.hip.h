@@ -239,6 +239,7 @@ __global__ __launch_bounds__(QPB * G) __attribute__((amdgpu_waves_per_eu(kWaveWa
     wave_table_pad<T, G>(table, M, rsub);
     if (bad | !(chk == T(0))) tab.bad[qa] = 1;
     __syncthreads();
+    // (the first scan is not taken while the rows are formed, as k_wave does: this kernel has no register to spare for it)
     const Pivot<T> s = wave_active_set_<T, G>(M, g, tab.rows + (size_t)qs * stride, tab.bad[qs]);
     if (g == 0) {
         tab.answer[2 * qs] = s.w0;

@@ -237,8 +237,10 @@ __host__ __device__ inline int wave_table_stride(int M, int G) { return (3 * wav
 // comes from a max over the group, the pivot reads it by index (broadcast reads).  Keys as in active_set_:
 // violation in the high bits, 1023 - row below, compared as signed integers; the threshold is applied once, to
 // the winner.  The trip count is wave-uniform; the groups of a wavefront commit under `go`.
-template <typename T, int G>
-__device__ inline Pivot<T> wave_active_set_(int M, int g, const T* s_rows, int bad)
+// FIRST_GIVEN: first_key is the winner of the scan at w = 0 (where a row's violation is its bt), which the threads that
+// formed the rows have already taken (wave_first_key_), and the first turn of the loop needs no scan.
+template <typename T, int G, bool FIRST_GIVEN = false>
+__device__ inline Pivot<T> wave_active_set_(int M, int g, const T* s_rows, int bad, int first_key = 0)
 {
     Pivot<T> s;
     s.reset(bad ? SCCBF_STATUS_NONFINITE : SCCBF_STATUS_OPTIMAL);
@@ -247,15 +249,18 @@ __device__ inline Pivot<T> wave_active_set_(int M, int g, const T* s_rows, int b
     const T* mine = s_rows + 3 * g;
     for (int it = 0;; ++it) {  // wave-uniform loop
         const T thr = Lim<T>::viol_tol * (abs_(s.w0) + abs_(s.w1)) + Lim<T>::tiny_n2;
-        int kbest = (int)0x80000000u;
+        int kmax = first_key;
+        if (!FIRST_GIVEN || it > 0) {
+            int kbest = (int)0x80000000u;
 #pragma unroll 4
-        for (int i = 0; i < turns; ++i) {
-            const T* r = mine + 3 * G * i;
-            const T viol = r[2] - (r[0] * s.w0 + r[1] * s.w1);
-            const int key = (int)((viol_bits(viol, thr) & ~0x3FFu) | (unsigned)(1023 - g - G * i));
-            kbest = key > kbest ? key : kbest;
+            for (int i = 0; i < turns; ++i) {
+                const T* r = mine + 3 * G * i;
+                const T viol = r[2] - (r[0] * s.w0 + r[1] * s.w1);
+                const int key = (int)((viol_bits(viol, thr) & ~0x3FFu) | (unsigned)(1023 - g - G * i));
+                kbest = key > kbest ? key : kbest;
+            }
+            kmax = group_imax<G>(kbest);
         }
-        const int kmax = group_imax<G>(kbest);
         const bool go = (s.st == SCCBF_STATUS_OPTIMAL) & viol_key_above(kmax, thr, 0x3FFu);
         if (!__any(go)) break;  // every group of the wavefront is done
         if (it >= cap) {
@@ -274,6 +279,11 @@ template <typename T> __device__ inline void wave_table_put(T* table, int m, T t
     table[3 * m] = t0;
     table[3 * m + 1] = t1;
     table[3 * m + 2] = tb;
+}
+// The scan key of row m at w = 0, as wave_active_set_ forms it (violation = bt, threshold of a zero optimum).
+template <typename T> __device__ inline int wave_first_key_(int m, T tb)
+{
+    return (int)((viol_bits(tb, (T)Lim<T>::tiny_n2) & ~0x3FFu) | (unsigned)(1023 - m));
 }
 // Thread `rsub` of the G that form a QP's rows fills its share of the padding (fewer than G rows).
 template <typename T, int G> __device__ inline void wave_table_pad(T* table, int M, int rsub)
@@ -358,17 +368,19 @@ template <typename T> struct WaveTables {
     T* answer;    // QPB x (w0, w1)
     int* status;  // QPB
     int* bad;     // QPB
+    int* first;   // QPB: the largest scan key of the QP's rows at w = 0 (ds_max by the threads that form them)
     __device__ WaveTables(unsigned char* raw, int M, int qpb, int G)
     {
         rows = reinterpret_cast<T*>(raw);
         answer = rows + (size_t)qpb * wave_table_stride(M, G);
         status = reinterpret_cast<int*>(answer + 2 * qpb);
         bad = status + qpb;
+        first = bad + qpb;
     }
 };
 template <typename T> __host__ __device__ inline size_t wave_lds_bytes(int M, int qpb, int G)
 {
-    return ((size_t)qpb * wave_table_stride(M, G) + 2 * qpb) * sizeof(T) + 2 * qpb * sizeof(int);
+    return ((size_t)qpb * wave_table_stride(M, G) + 2 * qpb) * sizeof(T) + 3 * qpb * sizeof(int);
 }
 
 // First agent of a workgroup.  PAIRED: the workgroup takes half of the agents that share a line, and the
@@ -401,7 +413,10 @@ __device__ inline void wave_body_(const KArgs<T>& p, unsigned block, unsigned ch
     long long qp = wave_first_agent<QPB, PAIRED>(block) + qa;
     const bool live = qp < p.A;
     if (!live) qp = p.A - 1;  // the thread stays for the barriers; its stores are masked
-    if (threadIdx.x < QPB) tab.bad[threadIdx.x] = 0;
+    if (threadIdx.x < QPB) {
+        tab.bad[threadIdx.x] = 0;
+        tab.first[threadIdx.x] = (int)0x80000000u;
+    }
 
     Ego<T> e;
     T ur0, ur1;
@@ -411,6 +426,7 @@ __device__ inline void wave_body_(const KArgs<T>& p, unsigned block, unsigned ch
 
     T* table = tab.rows + (size_t)qa * stride;
     T chk = T(0);  // stays 0 while every row is finite
+    int kfirst = (int)0x80000000u;
     staged_rows_<T, RS, QP_ONLY>(p, qp, rsub, [&](int m, const v4& oa, const v4& ob, int ty) {
         T a0, a1, b, h;
         if (QP_ONLY) {
@@ -424,11 +440,14 @@ __device__ inline void wave_body_(const KArgs<T>& p, unsigned block, unsigned ch
         T t0, t1, tb;
         to_wspace_(a0, a1, b, e, p, t0, t1, tb);
         wave_table_put(table, m, t0, t1, tb);
+        const int key = wave_first_key_(m, tb);
+        kfirst = key > kfirst ? key : kfirst;
     });
     wave_table_pad<T, G>(table, M, rsub);
+    atomicMax(&tab.first[qa], kfirst);
     if (bad | !(chk == T(0))) tab.bad[qa] = 1;
     __syncthreads();
-    const Pivot<T> s = wave_active_set_<T, G>(M, g, tab.rows + (size_t)qs * stride, tab.bad[qs]);
+    const Pivot<T> s = wave_active_set_<T, G, true>(M, g, tab.rows + (size_t)qs * stride, tab.bad[qs], tab.first[qs]);
     if (g == 0) {
         tab.answer[2 * qs] = s.w0;
         tab.answer[2 * qs + 1] = s.w1;
