@@ -29,7 +29,7 @@ rm -rf gpurun_out/r3_f64_pmc.d
 # long obstacle lists: launch times of every model from per-agent lists and from tiles, then the counters of the three kernel families
 for L in agents tiles; do
   echo "== layout $L" >> gpurun_out/r3_rows_sweep.txt
-  timeout -k 10 500 python -u tools/bench_rows.py --layout $L --rows 16,64,128,129,200,257,512,1024 2>&1 | grep "^M" >> gpurun_out/r3_rows_sweep.txt
+  timeout -k 10 500 python -u tools/bench_rows.py --layout $L --rows 16,64,128,129,200,256,257,512,1024 2>&1 | grep "^M" >> gpurun_out/r3_rows_sweep.txt
 done
 LAYOUT=agents bash tools/prof_rows_pmc.sh 128 257 1024
 LAYOUT=tiles bash tools/prof_rows_pmc.sh 128 257 1024
