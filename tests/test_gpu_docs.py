@@ -72,6 +72,30 @@ po, pt = flt.prepare_obs(obs.clone(), obs_type.clone())
 up, sp = flt.solve(state, u_ref, po, pt)
 assert (sp != status).sum() <= 1 and float((up - u).abs().max()) < 1e-2 * (1 + float(u.abs().max()))
 
+# ---- several batches in one launch, per-agent lists, least violation
+from sccav_cbf_amd import batched
+from sccav_cbf_amd.batched import BatchTable, planes_to_agents
+batched.prewarm()
+table = BatchTable([dict(state=state, u_ref=u_ref, obs=obs, obs_type=obs_type),
+                    dict(state=state[:300].contiguous(), u_ref=u_ref[:300].contiguous(), obs=obs[:, :, :300].contiguous(), obs_type=obs_type)])
+flt.solve_batches(table)
+torch.cuda.synchronize()
+assert torch.equal(table.batches[0]["u_out"], u) and torch.equal(table.batches[1]["u_out"], u[:300])
+for b in table.batches:
+    b["u_out"].zero_()
+flt.solve_batches_static(table)
+torch.cuda.synchronize()
+assert torch.equal(table.batches[0]["u_out"], u) and torch.equal(table.batches[1]["status"], status[:300])
+ul, sl = flt.solve(state, u_ref, planes_to_agents(obs), obs_type)      # obs as (A, M, 2, 4)
+assert torch.equal(ul, u) and torch.equal(sl, status)
+umv, smv, rows_mv = BatchedCBF(alpha=1.0, lr=1.45, lf=1.45, R=np.diag([0.5, 0.5]), min_violation=True).solve(state, u_ref, obs, obs_type)
+torch.cuda.synchronize()
+assert torch.equal(smv, status) and torch.equal(umv[status == 0], u[status == 0]) and rows_mv.shape == (5, A, 4)
+cbf_controller.infeasible_policy = "min_violation"
+assert len(cbf_controller.solve_cbf(np.array([0.3, 0.1]))) == 2
+lane7 = PolyLane([4.0, 0.01, 1e-3, 1e-5, 1e-7, 0.0, 1e-11], s, buffer=1.5)       # degree 6
+assert np.isfinite(lane7.f())
+
 # ---- closed loop
 from sccav_cbf_amd.nominal import BatchedNominal, ClosedLoop
 T = 12
