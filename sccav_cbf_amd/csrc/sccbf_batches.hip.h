@@ -61,7 +61,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kGroupWa
 }
 
 template <typename T, int QPB, int G, bool PAIRED>
-__global__ __launch_bounds__(QPB * G) __attribute__((amdgpu_waves_per_eu(kWaveWaves<T>))) void k_wave_batches(const sccbf_batch* table, int M, unsigned flags,
+__global__ __launch_bounds__(QPB * G) __attribute__((amdgpu_waves_per_eu(kWaveWaves<T, G>))) void k_wave_batches(const sccbf_batch* table, int M, unsigned flags,
                                                           const KArgs<T> rest)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];

@@ -199,10 +199,14 @@ __global__ __launch_bounds__(kBlock) void k_group_ext(const KArgs<T> p, const XA
     ext_epilogue_(p, x, qp, q, s.st, s.w0, s.w1);
 }
 
+// This kernel carries more per agent than k_wave (the slip state, its sines and cosines): held to the 96 registers of five
+// wavefronts per SIMD it spills and runs 10 - 15 % slower than at four (128 registers), with 16, 32 and 64 lanes per QP alike.
+template <typename T> constexpr int kWaveExtWaves = sizeof(T) == 4 ? 4 : 1;
+
 // G lanes per QP, rows staged in LDS only: any M up to SCCBF_MAX_ROWS (k_wave for these models, the same
 // two thread layouts).
 template <typename T, int QPB, int G, bool PAIRED = false>
-__global__ __launch_bounds__(QPB * G) __attribute__((amdgpu_waves_per_eu(kWaveWaves<T>))) void k_wave_ext(const KArgs<T> p, const XArgs<T> x)
+__global__ __launch_bounds__(QPB * G) __attribute__((amdgpu_waves_per_eu(kWaveExtWaves<T>))) void k_wave_ext(const KArgs<T> p, const XArgs<T> x)
 {
     using v4 = typename VT<T>::v4;
     using v2 = typename VT<T>::v2;
@@ -217,7 +221,11 @@ __global__ __launch_bounds__(QPB * G) __attribute__((amdgpu_waves_per_eu(kWaveWa
     long long qp = wave_first_agent<QPB, PAIRED>() + qa;
     const bool live = qp < p.A;
     if (!live) qp = p.A - 1;  // the thread stays for the barriers; its stores are masked
-    if (threadIdx.x < QPB) tab.bad[threadIdx.x] = 0;
+    constexpr bool kFirst = true;  // the first scan is taken while the rows are formed, as in k_wave
+    if (threadIdx.x < QPB) {
+        tab.bad[threadIdx.x] = 0;
+        tab.first[threadIdx.x] = (int)0x80000000u;
+    }
 
     ExtEgo<T> q;
     ext_prologue_(p, x, qp, reinterpret_cast<const v4*>(p.state)[qp], reinterpret_cast<const v2*>(p.u_ref)[qp], q);
@@ -226,6 +234,7 @@ __global__ __launch_bounds__(QPB * G) __attribute__((amdgpu_waves_per_eu(kWaveWa
 
     T* table = tab.rows + (size_t)qa * stride;
     T chk = T(0);  // stays 0 while every row is finite
+    int kfirst = (int)0x80000000u;
     staged_rows_<T, G, false>(p, qp, rsub, [&](int m, const v4& oa, const v4& ob, int ty) {
         T o[8] = {oa.x, oa.y, oa.z, oa.w, ob.x, ob.y, ob.z, ob.w};
         T a0, a1, b, h;
@@ -235,12 +244,16 @@ __global__ __launch_bounds__(QPB * G) __attribute__((amdgpu_waves_per_eu(kWaveWa
         T t0, t1, tb;
         to_wspace_(a0, a1, b, q.e, p, t0, t1, tb);
         wave_table_put(table, m, t0, t1, tb);
+        if (kFirst) {
+            const int key = wave_first_key_(m, tb);
+            kfirst = key > kfirst ? key : kfirst;
+        }
     });
     wave_table_pad<T, G>(table, M, rsub);
+    if (kFirst) atomicMax(&tab.first[qa], kfirst);
     if (bad | !(chk == T(0))) tab.bad[qa] = 1;
     __syncthreads();
-    // (the first scan is not taken while the rows are formed, as k_wave does: this kernel has no register to spare for it)
-    const Pivot<T> s = wave_active_set_<T, G>(M, g, tab.rows + (size_t)qs * stride, tab.bad[qs]);
+    const Pivot<T> s = wave_active_set_<T, G, kFirst>(M, g, tab.rows + (size_t)qs * stride, tab.bad[qs], tab.first[qs]);
     if (g == 0) {
         tab.answer[2 * qs] = s.w0;
         tab.answer[2 * qs + 1] = s.w1;

@@ -458,15 +458,16 @@ __device__ inline void wave_body_(const KArgs<T>& p, unsigned block, unsigned ch
         store_result_(p, qp, QP_ONLY, tab.status[qa], tab.answer[2 * qa], tab.answer[2 * qa + 1], e, ur0, ur1);
 }
 
-// Wavefronts per SIMD the register allocation of this family is held to (at least): the fp32 kernels sit at
-// 94 ... 100 registers, the 96 of five wavefronts within reach; fp64 is left alone.
+// Wavefronts per SIMD the register allocation of this family is held to (at least), fp32: five (96 registers) while
+// four-wavefront workgroups (16 or 32 lanes per QP) are what fills a CU; the workgroups of 64 lanes per QP come two
+// or three to a CU by their LDS tables whatever the registers up to 128, so those kernels may use them.  fp64 is left alone.
 #ifndef SCCBF_WAVE_WAVES_F32
 #define SCCBF_WAVE_WAVES_F32 5
 #endif
-template <typename T> constexpr int kWaveWaves = sizeof(T) == 4 ? SCCBF_WAVE_WAVES_F32 : 1;
+template <typename T, int G = 32> constexpr int kWaveWaves = sizeof(T) == 4 ? (G == 64 ? 4 : SCCBF_WAVE_WAVES_F32) : 1;
 
 template <typename T, int QPB, bool QP_ONLY, int G, bool PAIRED = false>
-__global__ __launch_bounds__(QPB * G) __attribute__((amdgpu_waves_per_eu(kWaveWaves<T>))) void k_wave(const KArgs<T> p)
+__global__ __launch_bounds__(QPB * G) __attribute__((amdgpu_waves_per_eu(kWaveWaves<T, G>))) void k_wave(const KArgs<T> p)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     wave_body_<T, QPB, QP_ONLY, G, PAIRED>(p, blockIdx.x, smem_raw);
