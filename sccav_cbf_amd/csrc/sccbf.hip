@@ -208,9 +208,11 @@ template <typename T> size_t wave_lds(int M, int qpb, int G) { return wave_lds_b
 // while five workgroups fit a CU (the kernels run five wavefronts per SIMD; up to 160 fp32 rows: 69 against 74 us at
 // 160 rows, 95 against 89 at 200), 32 while four do (up to 416: 147 against 164 us at 350 rows), else a wavefront per
 // QP, whose workgroups have twice the wavefronts for the same tables
-template <typename T> int wave_lanes(int M)
+// fit16: workgroups of 16-lane groups a CU must hold for 16 lanes to be chosen: five for k_wave, four for k_wave_ext, which runs
+// four wavefronts per SIMD (unicycle model: 88 against 94 us at 200 rows)
+template <typename T> int wave_lanes(int M, int fit16 = 5)
 {
-    if (wave_lds<T>(M, WaveShape<T, 16>::kQpb, 16) * 5 <= kLdsPerCu) return 16;
+    if (wave_lds<T>(M, WaveShape<T, 16>::kQpb, 16) * fit16 <= kLdsPerCu) return 16;
     if (wave_lds<T>(M, WaveShape<T, 32>::kQpb, 32) * 4 <= kLdsPerCu) return 32;
     return 64;
 }
@@ -334,7 +336,7 @@ int dispatch_ext(const sccbf_params* sp, const KArgs<T>& k, const XArgs<T>& x, v
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     int lanes = sp->lanes_per_qp;
     if (lanes == 0) {  // as for the bicycle models (auto_lanes)
-        if (k.M > 128) lanes = wave_lanes<T>(k.M);
+        if (k.M > 128) lanes = wave_lanes<T>(k.M, 4);
         else if ((k.flags & SCCBF_FLAG_OBS_AGENT_MAJOR) && k.M > 64) lanes = 16;
         else if (k.A >= (1 << 13)) lanes = k.M <= 16 ? 4 : 8;
         else lanes = 16;
