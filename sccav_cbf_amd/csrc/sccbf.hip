@@ -145,7 +145,9 @@ int fill_args(const sccbf_params* sp, int64_t A, int32_t M, KArgs<T>& k)
 // registers: 98 against 116 us at 200 rows, 116 against 130 at 256)
 // From per-agent lists 16 lanes read runs of 16 consecutive slots of an agent: 65 ... 128 rows, 65536 QPs:
 // 44 against 57 us at 96 rows, 53 against 63 at 128 (from tiles 8 lanes: 50 and 59).
-int auto_lanes(int64_t A, int M, uint32_t flags)
+// fp64: at most 8 rows per lane (16 rows of doubles need 365 registers: 8 lanes x 16 rows took 629 us at 128 rows where
+// 16 lanes x 8 rows take 124).
+int auto_lanes(int64_t A, int M, uint32_t flags, int scalar_bytes)
 {
     if (M > 128) return 64;  // rows in LDS only; wave_lanes() then picks the group
     if ((flags & SCCBF_FLAG_OBS_AGENT_MAJOR) && M > 64) return 16;
@@ -153,7 +155,8 @@ int auto_lanes(int64_t A, int M, uint32_t flags)
     if (A >= (1 << 15)) g = M <= 16 ? 4 : 8;
     else if (A >= (1 << 13)) g = 8;
     else g = 16;
-    while (g < 16 && M > 16 * g) g *= 2;  // keep at most 16 rows per lane
+    const int rows_per_lane = scalar_bytes == 8 ? 8 : 16;
+    while (g < 16 && M > rows_per_lane * g) g *= 2;
     return g;
 }
 
@@ -248,12 +251,26 @@ template <int QPB, bool PAIRED> long long wave_blocks(long long A)
 // them per workgroup, paired on an XCD
 template <typename T> bool wave_paired(int M) { return wave_lds<T>(M, WaveShape<T, 64>::kQpb, 64) * 2 > kLdsPerCu; }
 
+// fp64: the kernels that stage one slot per load batch instead of two use fewer registers (three wavefronts per SIMD
+// instead of two): taken where a workgroup's LDS tables leave room for more than eight wavefronts per CU, else the
+// deeper ones, whose wavefronts cover more of their own latency.  fp32 has one depth.
+template <typename T> bool wave_shallow(size_t lds, int threads)
+{
+    return sizeof(T) == 8 && (kLdsPerCu / lds) * (size_t)(threads / 64) > 8;
+}
+
 template <typename T, bool QP_ONLY, int G, int QPB, bool PAIRED>
 int launch_wave_shape(const KArgs<T>& k, hipStream_t s)
 {
     const size_t lds = wave_lds<T>(k.M, QPB, G);
     const long long blocks = wave_blocks<QPB, PAIRED>(k.A);
     if (blocks > 0x7fffffffLL) return SCCBF_ERR_ARG;
+    if (wave_shallow<T>(lds, QPB * G)) {
+        constexpr int kNb = kWaveBatchShallow<T>;
+        if (!grant_lds<k_wave<T, QPB, QP_ONLY, G, PAIRED, kNb>>(lds)) return SCCBF_ERR_VARIANT;
+        launch_((k_wave<T, QPB, QP_ONLY, G, PAIRED, kNb>), dim3((unsigned)blocks), dim3(QPB * G), lds, s, k);
+        return launched_();
+    }
     if (!grant_lds<k_wave<T, QPB, QP_ONLY, G, PAIRED>>(lds)) return SCCBF_ERR_VARIANT;
     launch_((k_wave<T, QPB, QP_ONLY, G, PAIRED>), dim3((unsigned)blocks), dim3(QPB * G), lds, s, k);
     return launched_();
@@ -279,7 +296,7 @@ int dispatch(const sccbf_params* sp, KArgs<T>& k, void* stream)
         return launched_();
     }
     int lanes = sp->lanes_per_qp;
-    if (lanes == 0) lanes = auto_lanes(k.A, k.M, k.flags);
+    if (lanes == 0) lanes = auto_lanes(k.A, k.M, k.flags, (int)sizeof(T));
     if (lanes == 64 && sp->lanes_per_qp == 0) lanes = wave_lanes<T>(k.M);
     switch (lanes) {
     case 1: return launch_group_rpl<T, QP_ONLY, 1>(k, s);
@@ -317,6 +334,12 @@ int launch_wave_ext_shape(const KArgs<T>& k, const XArgs<T>& x, hipStream_t s)
     const size_t lds = wave_lds<T>(k.M, QPB, G);
     const long long blocks = wave_blocks<QPB, PAIRED>(k.A);
     if (blocks > 0x7fffffffLL) return SCCBF_ERR_ARG;
+    if (wave_shallow<T>(lds, QPB * G)) {
+        constexpr int kNb = kWaveBatchShallow<T>;
+        if (!grant_lds<k_wave_ext<T, QPB, G, PAIRED, kNb>>(lds)) return SCCBF_ERR_VARIANT;
+        launch_((k_wave_ext<T, QPB, G, PAIRED, kNb>), dim3((unsigned)blocks), dim3(QPB * G), lds, s, k, x);
+        return launched_();
+    }
     if (!grant_lds<k_wave_ext<T, QPB, G, PAIRED>>(lds)) return SCCBF_ERR_VARIANT;
     launch_((k_wave_ext<T, QPB, G, PAIRED>), dim3((unsigned)blocks), dim3(QPB * G), lds, s, k, x);
     return launched_();
@@ -337,7 +360,7 @@ int dispatch_ext(const sccbf_params* sp, const KArgs<T>& k, const XArgs<T>& x, v
     int lanes = sp->lanes_per_qp;
     if (lanes == 0) {  // as for the bicycle models (auto_lanes)
         if (k.M > 128) lanes = wave_lanes<T>(k.M, 4);
-        else if ((k.flags & SCCBF_FLAG_OBS_AGENT_MAJOR) && k.M > 64) lanes = 16;
+        else if (((k.flags & SCCBF_FLAG_OBS_AGENT_MAJOR) || sizeof(T) == 8) && k.M > 64) lanes = 16;   // fp64: at most 8 rows per lane
         else if (k.A >= (1 << 13)) lanes = k.M <= 16 ? 4 : 8;
         else lanes = 16;
     }
@@ -366,12 +389,17 @@ int launch_min_violation(const KArgs<T>& k, const T* rows, int transform, void* 
 template <typename T, int G> bool prewarm_wave_()
 {
     constexpr int kQpb = WaveShape<T, G>::kQpb;
+    constexpr int kHalf = G == 64 ? kQpb / 2 : kQpb;
+    constexpr int kNb = kWaveBatchShallow<T>;   // fp64: the second depth of every kernel (fp32: the same instantiation again)
     bool ok = grant_lds<k_wave<T, kQpb, false, G, false>>(kLdsPerCu) & grant_lds<k_wave<T, kQpb, true, G, false>>(kLdsPerCu) &
-              grant_lds<k_wave_ext<T, kQpb, G, false>>(kLdsPerCu);
+              grant_lds<k_wave_ext<T, kQpb, G, false>>(kLdsPerCu) &
+              grant_lds<k_wave<T, kQpb, false, G, false, kNb>>(kLdsPerCu) & grant_lds<k_wave<T, kQpb, true, G, false, kNb>>(kLdsPerCu) &
+              grant_lds<k_wave_ext<T, kQpb, G, false, kNb>>(kLdsPerCu);
     if (G == 64)
-        ok &= grant_lds<k_wave<T, (G == 64 ? kQpb / 2 : kQpb), false, G, G == 64>>(kLdsPerCu) &
-              grant_lds<k_wave<T, (G == 64 ? kQpb / 2 : kQpb), true, G, G == 64>>(kLdsPerCu) &
-              grant_lds<k_wave_ext<T, (G == 64 ? kQpb / 2 : kQpb), G, G == 64>>(kLdsPerCu);
+        ok &= grant_lds<k_wave<T, kHalf, false, G, G == 64>>(kLdsPerCu) & grant_lds<k_wave<T, kHalf, true, G, G == 64>>(kLdsPerCu) &
+              grant_lds<k_wave_ext<T, kHalf, G, G == 64>>(kLdsPerCu) &
+              grant_lds<k_wave<T, kHalf, false, G, G == 64, kNb>>(kLdsPerCu) &
+              grant_lds<k_wave<T, kHalf, true, G, G == 64, kNb>>(kLdsPerCu) & grant_lds<k_wave_ext<T, kHalf, G, G == 64, kNb>>(kLdsPerCu);
     return ok;
 }
 template <typename T> int prewarm_part_()
@@ -735,6 +763,13 @@ int launch_wave_batches_shape(const KArgs<T>& k, const sccbf_batch* table, int K
     const size_t lds = wave_lds<T>(k.M, QPB, G);
     const long long bx = wave_blocks<QPB, PAIRED>(a_max);
     if (bx > 0x7fffffffLL) return SCCBF_ERR_ARG;
+    if (wave_shallow<T>(lds, QPB * G)) {
+        constexpr int kNb = kWaveBatchShallow<T>;
+        if (!grant_lds<k_wave_batches<T, QPB, G, PAIRED, kNb>>(lds)) return SCCBF_ERR_VARIANT;
+        launch_((k_wave_batches<T, QPB, G, PAIRED, kNb>), dim3((unsigned)bx, (unsigned)K), dim3(QPB * G), lds, s, table,
+                           k.M, k.flags, k);
+        return launched_();
+    }
     if (!grant_lds<k_wave_batches<T, QPB, G, PAIRED>>(lds)) return SCCBF_ERR_VARIANT;
     launch_((k_wave_batches<T, QPB, G, PAIRED>), dim3((unsigned)bx, (unsigned)K), dim3(QPB * G), lds, s, table,
                        k.M, k.flags, k);
@@ -776,7 +811,7 @@ int batches_launch(const sccbf_params* sp, int32_t K, int32_t M, int64_t a_max, 
     const double total = (double)a_max * K;
     const int64_t a_all = total > 2147483647.0 ? 0x7fffffffLL : (int64_t)total;
     int lanes = sp->lanes_per_qp;
-    if (lanes == 0) lanes = auto_lanes(a_all, M, sp->flags);
+    if (lanes == 0) lanes = auto_lanes(a_all, M, sp->flags, (int)sizeof(T));
     if (lanes == 64 && sp->lanes_per_qp == 0) lanes = wave_lanes<T>(M);
     const bool nt = (sp->flags & SCCBF_FLAG_OBS_STREAMED) || total * M * 8 * sizeof(T) >= kNtBytes;
     switch (lanes) {
@@ -842,8 +877,11 @@ __global__ __launch_bounds__(kFillBatches * 8) void k_table_fill(sccbf_batch* ds
 template <typename T, int G> bool prewarm_wave_batches_()
 {
     constexpr int kQpb = WaveShape<T, G>::kQpb;
-    bool ok = grant_lds<k_wave_batches<T, kQpb, G, false>>(kLdsPerCu);
-    if (G == 64) ok &= grant_lds<k_wave_batches<T, (G == 64 ? kQpb / 2 : kQpb), G, G == 64>>(kLdsPerCu);
+    constexpr int kNb = kWaveBatchShallow<T>;
+    bool ok = grant_lds<k_wave_batches<T, kQpb, G, false>>(kLdsPerCu) & grant_lds<k_wave_batches<T, kQpb, G, false, kNb>>(kLdsPerCu);
+    if (G == 64)
+        ok &= grant_lds<k_wave_batches<T, (G == 64 ? kQpb / 2 : kQpb), G, G == 64>>(kLdsPerCu) &
+              grant_lds<k_wave_batches<T, (G == 64 ? kQpb / 2 : kQpb), G, G == 64, kNb>>(kLdsPerCu);
     return ok;
 }
 

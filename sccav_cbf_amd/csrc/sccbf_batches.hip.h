@@ -60,7 +60,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kGroupWa
     group_solve_<T, G, RPL, false>(p, qp, g, L);
 }
 
-template <typename T, int QPB, int G, bool PAIRED>
+template <typename T, int QPB, int G, bool PAIRED, int NB = kWaveBatch<T>>
 __global__ __launch_bounds__(QPB * G) __attribute__((amdgpu_waves_per_eu(kWaveWaves<T, G>))) void k_wave_batches(const sccbf_batch* table, int M, unsigned flags,
                                                           const KArgs<T> rest)
 {
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(QPB * G) __attribute__((amdgpu_waves_per_eu(kWaveWa
     // the grid is sized like k_wave's for the largest batch (a multiple of 16 workgroups when PAIRED): the
     // workgroups past this batch's last agent leave together, whole pairs of them
     if (wave_first_agent<QPB, PAIRED>(blockIdx.x & ~(PAIRED ? 15u : 0u)) >= p.A) return;
-    wave_body_<T, QPB, false, G, PAIRED>(p, blockIdx.x, smem_raw);
+    wave_body_<T, QPB, false, G, PAIRED, NB>(p, blockIdx.x, smem_raw);
 }
 
 // no rows at all: the nominal input is optimal

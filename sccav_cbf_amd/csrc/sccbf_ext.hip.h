@@ -205,7 +205,7 @@ template <typename T> constexpr int kWaveExtWaves = sizeof(T) == 4 ? 4 : 1;
 
 // G lanes per QP, rows staged in LDS only: any M up to SCCBF_MAX_ROWS (k_wave for these models, the same
 // two thread layouts).
-template <typename T, int QPB, int G, bool PAIRED = false>
+template <typename T, int QPB, int G, bool PAIRED = false, int NB = kWaveBatch<T>>
 __global__ __launch_bounds__(QPB * G) __attribute__((amdgpu_waves_per_eu(kWaveExtWaves<T>))) void k_wave_ext(const KArgs<T> p, const XArgs<T> x)
 {
     using v4 = typename VT<T>::v4;
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(QPB * G) __attribute__((amdgpu_waves_per_eu(kWaveEx
     T* table = tab.rows + (size_t)qa * stride;
     T chk = T(0);  // stays 0 while every row is finite
     int kfirst = (int)0x80000000u;
-    staged_rows_<T, G, false>(p, qp, rsub, [&](int m, const v4& oa, const v4& ob, int ty) {
+    staged_rows_<T, G, false, NB>(p, qp, rsub, [&](int m, const v4& oa, const v4& ob, int ty) {
         T o[8] = {oa.x, oa.y, oa.z, oa.w, ob.x, ob.y, ob.z, ob.w};
         T a0, a1, b, h;
         ext_slot_row_(ty, o, q.e, p, q.sadbm, q.cone_beta_state, q.sl.x, q.cthb, q.sthb, q.sb, a0, a1, b, h);

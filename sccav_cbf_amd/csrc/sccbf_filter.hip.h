@@ -299,23 +299,28 @@ template <typename T, int G> __device__ inline void wave_table_pad(T* table, int
 // slot of the two batches, four copies, the kernels stay within 96 registers (five wavefronts per SIMD) and
 // spill nothing; four per batch take 128 registers and are 8 % slower, eight (80 KB of code, more than the
 // instruction cache holds) three times slower.
+// fp64: 195 registers with two slots per batch (two wavefronts per SIMD), fewer with one: the kernels come in both
+// depths (template parameter NB) and the host launches the shallow one where the LDS tables leave room for more than
+// two wavefronts per SIMD (257 rows: 339 -> 283 us, 512: 507 -> 440), the deep one where they do not and a wavefront
+// has to cover its own latency (1024 rows: 1072 against 1263 us).
 #ifndef SCCBF_WAVE_BATCH
 #define SCCBF_WAVE_BATCH 2
 #endif
-constexpr int kWaveBatch = SCCBF_WAVE_BATCH;
-template <typename T> struct SlotBatch {
-    typename VT<T>::v4 oa[kWaveBatch], ob[kWaveBatch];
-    int ty[kWaveBatch];
+template <typename T> constexpr int kWaveBatch = SCCBF_WAVE_BATCH;
+template <typename T> constexpr int kWaveBatchShallow = sizeof(T) == 8 ? 1 : kWaveBatch<T>;
+template <typename T, int NB> struct SlotBatch {
+    typename VT<T>::v4 oa[NB], ob[NB];
+    int ty[NB];
 };
 
-template <typename T, int G, bool QP_ONLY>
+template <typename T, int G, bool QP_ONLY, int NB>
 __device__ inline void batch_load_(const KArgs<T>& p, const ObsAddr& oad, long long qp, bool type_pa, int m0,
-                                   SlotBatch<T>& B)
+                                   SlotBatch<T, NB>& B)
 {
     using v4 = typename VT<T>::v4;
     const v4* obs4 = reinterpret_cast<const v4*>(p.obs);
 #pragma unroll
-    for (int k = 0; k < kWaveBatch; ++k) {
+    for (int k = 0; k < NB; ++k) {
         const int m = min(m0 + k * G, p.M - 1);  // past the end: a slot that exists, its row is dropped
         if (QP_ONLY) {
             B.oa[k] = obs4[(long long)m * p.A + qp];
@@ -328,26 +333,26 @@ __device__ inline void batch_load_(const KArgs<T>& p, const ObsAddr& oad, long l
     }
 }
 
-template <typename T, int G, bool QP_ONLY, typename RowFn>
+template <typename T, int G, bool QP_ONLY, int NB, typename RowFn>
 __device__ inline void staged_rows_(const KArgs<T>& p, long long qp, int g, RowFn row)
 {
     const bool type_pa = (p.flags & SCCBF_FLAG_TYPE_PER_AGENT) != 0;
     const ObsAddr oad = obs_addr_(p, qp);
-    constexpr int kStep = kWaveBatch * G;
+    constexpr int kStep = NB * G;
     const int M = p.M;
-    SlotBatch<T> b0, b1;
-    batch_load_<T, G, QP_ONLY>(p, oad, qp, type_pa, g, b0);
+    SlotBatch<T, NB> b0, b1;
+    batch_load_<T, G, QP_ONLY, NB>(p, oad, qp, type_pa, g, b0);
     for (int base = 0; base < M; base += 2 * kStep) {  // wave-uniform
-        if (base + kStep < M) batch_load_<T, G, QP_ONLY>(p, oad, qp, type_pa, base + kStep + g, b1);
+        if (base + kStep < M) batch_load_<T, G, QP_ONLY, NB>(p, oad, qp, type_pa, base + kStep + g, b1);
 #pragma unroll
-        for (int k = 0; k < kWaveBatch; ++k) {
+        for (int k = 0; k < NB; ++k) {
             const int m = base + k * G + g;
             if (m < M) row(m, b0.oa[k], b0.ob[k], b0.ty[k]);
         }
         if (base + kStep >= M) break;
-        if (base + 2 * kStep < M) batch_load_<T, G, QP_ONLY>(p, oad, qp, type_pa, base + 2 * kStep + g, b0);
+        if (base + 2 * kStep < M) batch_load_<T, G, QP_ONLY, NB>(p, oad, qp, type_pa, base + 2 * kStep + g, b0);
 #pragma unroll
-        for (int k = 0; k < kWaveBatch; ++k) {
+        for (int k = 0; k < NB; ++k) {
             const int m = base + kStep + k * G + g;
             if (m < M) row(m, b1.oa[k], b1.ob[k], b1.ty[k]);
         }
@@ -398,7 +403,7 @@ template <int QPB, bool PAIRED> __device__ inline long long wave_first_agent(uns
 // The work of one workgroup on the QPB agents from wave_first_agent(block) on; smem_raw: the workgroup's dynamic
 // LDS.  A workgroup may call it again for another `block`: the tables it reads after its last barrier
 // (answer, status) are rewritten only after the next call's second barrier.
-template <typename T, int QPB, bool QP_ONLY, int G, bool PAIRED>
+template <typename T, int QPB, bool QP_ONLY, int G, bool PAIRED, int NB = kWaveBatch<T>>
 __device__ inline void wave_body_(const KArgs<T>& p, unsigned block, unsigned char* smem_raw)
 {
     using v4 = typename VT<T>::v4;
@@ -427,7 +432,7 @@ __device__ inline void wave_body_(const KArgs<T>& p, unsigned block, unsigned ch
     T* table = tab.rows + (size_t)qa * stride;
     T chk = T(0);  // stays 0 while every row is finite
     int kfirst = (int)0x80000000u;
-    staged_rows_<T, RS, QP_ONLY>(p, qp, rsub, [&](int m, const v4& oa, const v4& ob, int ty) {
+    staged_rows_<T, RS, QP_ONLY, NB>(p, qp, rsub, [&](int m, const v4& oa, const v4& ob, int ty) {
         T a0, a1, b, h;
         if (QP_ONLY) {
             a0 = oa.x; a1 = oa.y; b = oa.z; h = T(0);
@@ -466,11 +471,11 @@ __device__ inline void wave_body_(const KArgs<T>& p, unsigned block, unsigned ch
 #endif
 template <typename T, int G = 32> constexpr int kWaveWaves = sizeof(T) == 4 ? (G == 64 ? 4 : SCCBF_WAVE_WAVES_F32) : 1;
 
-template <typename T, int QPB, bool QP_ONLY, int G, bool PAIRED = false>
+template <typename T, int QPB, bool QP_ONLY, int G, bool PAIRED = false, int NB = kWaveBatch<T>>
 __global__ __launch_bounds__(QPB * G) __attribute__((amdgpu_waves_per_eu(kWaveWaves<T, G>))) void k_wave(const KArgs<T> p)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    wave_body_<T, QPB, QP_ONLY, G, PAIRED>(p, blockIdx.x, smem_raw);
+    wave_body_<T, QPB, QP_ONLY, G, PAIRED, NB>(p, blockIdx.x, smem_raw);
 }
 
 // ------------------------------------- barrier value and partials only (no rows, no QP)

@@ -18,31 +18,32 @@ from sccav_cbf_amd.batched import BatchedCBF, planes_to_agents, planes_to_tiled 
 from sccav_cbf_amd._lib import OBS_LANE as LANE  # noqa: E402
 
 
-def rows_ring(base, M, A, dev, layout="tiles", by_kind=False, nbytes=600_000_000):
+def rows_ring(base, M, A, dev, layout="tiles", by_kind=False, nbytes=600_000_000, dtype=torch.float32):
     """Distinct batches of A agents x M slots (more than twice the Infinity Cache together) made from the 16-slot
     batch `base` (scenarios.prepared(config4)): copy k of an obstacle stands 10 k .. 10 k + 10 m farther from the
     agent along the line of sight (lane slots stay as they are), so the feasible share of the batch stays that
     of 16 rows.  Returns (ring of dicts state / u_ref / obs, obs_type)."""
     reps = -(-M // 16)
     ring = []
-    nring = max(2, -(-nbytes // (A * (32 * M + 36))))
+    w = 4 if dtype == torch.float32 else 8
+    nring = max(2, -(-nbytes // (A * w * (8 * M + 9))))
     kinds = np.tile(base["obs_type"], reps)[:M]
     for b in range(nring):
         sh = 64 * 331 * (b + 1)
-        obs = torch.from_numpy(np.roll(base["obs"], sh, axis=2)).float().to(dev)
+        obs = torch.from_numpy(np.roll(base["obs"], sh, axis=2)).to(dtype).to(dev)
         obs = obs.repeat(reps, 1, 1, 1)[:M].contiguous()
-        ego = torch.from_numpy(np.roll(base["state"], sh, axis=0)[:, 0:2]).float().to(dev)
+        ego = torch.from_numpy(np.roll(base["state"], sh, axis=0)[:, 0:2]).to(dtype).to(dev)
         is_lane = torch.from_numpy(kinds == LANE).to(dev)
         los = obs[:, 0, :, 0:2] - ego[None]
         los = los / los.norm(dim=2, keepdim=True).clamp_min(1e-3)
-        far = (torch.arange(M, device=dev) // 16).float()[:, None, None] * 10.0
-        far = far + 10.0 * torch.rand((M, 1, 1), device=dev) * (far > 0)
+        far = (torch.arange(M, device=dev) // 16).to(dtype)[:, None, None] * 10.0
+        far = far + 10.0 * torch.rand((M, 1, 1), device=dev, dtype=dtype) * (far > 0)
         obs[:, 0, :, 0:2] += torch.where(is_lane[:, None, None], torch.zeros_like(los), los * far)
         if by_kind:
             order = torch.from_numpy(np.argsort(kinds, kind="stable")).to(dev)
             obs = obs[order].contiguous()
-        ring.append(dict(state=torch.from_numpy(np.roll(base["state"], sh, axis=0)).float().to(dev),
-                         u_ref=torch.from_numpy(np.roll(base["u_ref"], sh, axis=0)).float().to(dev),
+        ring.append(dict(state=torch.from_numpy(np.roll(base["state"], sh, axis=0)).to(dtype).to(dev),
+                         u_ref=torch.from_numpy(np.roll(base["u_ref"], sh, axis=0)).to(dtype).to(dev),
                          obs={"tiles": planes_to_tiled, "agents": planes_to_agents,
                               "planes": lambda o: o}[layout](obs)))
         del obs
@@ -56,9 +57,10 @@ def time_rows(f, ring, ty, A, M, branches=1, **kw):
     from sccav_cbf_amd.batched import capture_independent
     dev = ty.device
     nring = len(ring)
-    abytes = A * (4 * (4 + 2 + 8 * M + 2) + 4)
+    w = ring[0]["state"].element_size()
+    abytes = A * (w * (4 + 2 + 8 * M + 2) + 4)
     inner = max(1, 10 // nring)   # about 10 launches per captured walk: a replay's own start is a small share
-    outs = [(torch.empty((A, 2), device=dev), torch.empty((A,), dtype=torch.int32, device=dev))
+    outs = [(torch.empty((A, 2), device=dev, dtype=ring[0]["state"].dtype), torch.empty((A,), dtype=torch.int32, device=dev))
             for _ in ring * inner]   # launches may overlap
     steps = [(lambda b=b, o=o: f.solve(b["state"], b["u_ref"], b["obs"], ty, u_out=o[0], status=o[1], **kw))
              for b, o in zip(ring * inner, outs)]
@@ -94,6 +96,7 @@ def main():
     ap.add_argument("--models", default="dbm,kbm,dum,sadbm")
     ap.add_argument("--layout", default="tiles", choices=("tiles", "agents", "planes"),
                     help="obstacle layout: 64-agent tiles, per-agent lists (A,M,2,4) or planes (M,2,A,4)")
+    ap.add_argument("--dtype", default="f32", choices=("f32", "f64"))
     ap.add_argument("--sorted", action="store_true", help="slots grouped by kind instead of 8 + 8 repeated")
     ap.add_argument("--branches", type=int, default=1,
                     help="parallel branches of the captured walk: the launches are independent batches")
@@ -103,8 +106,9 @@ def main():
     base = scenarios.prepared(scenarios.config4(A=A, nominal="uniform", seed=3))
     torch.manual_seed(1)
     for M in [int(m) for m in args.rows.split(",")]:
-        ring, ty = rows_ring(base, M, A, dev, args.layout, args.sorted)
-        slip = torch.zeros((A, 2), device=dev)
+        dt = torch.float32 if args.dtype == "f32" else torch.float64
+        ring, ty = rows_ring(base, M, A, dev, args.layout, args.sorted, dtype=dt)
+        slip = torch.zeros((A, 2), device=dev, dtype=dt)
         for name, lanes in [(n, int(l)) for n in args.models.split(",") for l in args.lanes.split(",")]:
             f = BatchedCBF(alpha=1.0, R=np.diag([0.5, 0.5]), dynamics=name, streamed_obs=True, lanes_per_qp=lanes)
             kw = dict(slip=slip, dt=0.1) if name == "sadbm" else {}
