@@ -213,8 +213,11 @@ template <typename T> size_t wave_lds(int M, int qpb, int G) { return wave_lds_b
 // QP, whose workgroups have twice the wavefronts for the same tables
 // fit16: workgroups of 16-lane groups a CU must hold for 16 lanes to be chosen: five for k_wave, four for k_wave_ext, which runs
 // four wavefronts per SIMD (unicycle model: 88 against 94 us at 200 rows)
+// fp64 (two or three wavefronts per SIMD by the registers): 32 lanes while two workgroups fit (up to 416 rows: 194 against
+// 253 us at 200 rows, 380 against 399 at 400 for 64 lanes), else 64.
 template <typename T> int wave_lanes(int M, int fit16 = 5)
 {
+    if (sizeof(T) == 8) return wave_lds<T>(M, WaveShape<T, 32>::kQpb, 32) * 2 <= kLdsPerCu ? 32 : 64;
     if (wave_lds<T>(M, WaveShape<T, 16>::kQpb, 16) * fit16 <= kLdsPerCu) return 16;
     if (wave_lds<T>(M, WaveShape<T, 32>::kQpb, 32) * 4 <= kLdsPerCu) return 32;
     return 64;
