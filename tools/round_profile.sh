@@ -31,5 +31,11 @@ for L in agents tiles; do
   echo "== layout $L" >> gpurun_out/r3_rows_sweep.txt
   timeout -k 10 500 python -u tools/bench_rows.py --layout $L --rows 16,64,128,129,200,256,257,512,1024 2>&1 | grep "^M" >> gpurun_out/r3_rows_sweep.txt
 done
+# the same sweep in double precision (bicycle and unicycle models)
+: > gpurun_out/r3_rows_sweep_f64.txt
+for L in agents tiles; do
+  echo "== layout $L" >> gpurun_out/r3_rows_sweep_f64.txt
+  timeout -k 10 500 python -u tools/bench_rows.py --dtype f64 --layout $L --rows 16,64,128,129,200,257,512,1024 --models dbm,dum 2>&1 | grep "^M" >> gpurun_out/r3_rows_sweep_f64.txt
+done
 LAYOUT=agents bash tools/prof_rows_pmc.sh 128 257 1024
 LAYOUT=tiles bash tools/prof_rows_pmc.sh 128 257 1024
