@@ -2,7 +2,7 @@
 """K batches of the bench workload (65536 agents x 16 rows, tiled prepared slots) in ONE launch
 (sccbf_solve_batches_*) against one launch per batch: microseconds per batch and share of 8 TB/s.
 
-    python tools/bench_batches.py [--dtype f32|f64] [--agents 65536] [--rows 16] [--ring 20] [--lanes 0]
+    python tools/bench_batches.py [--dtype f32|f64] [--agents 65536] [--rows 16] [--ring 20] [--lanes 0] [--layout tiles|agents|planes]
 """
 import argparse
 import os
@@ -14,7 +14,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sccav_cbf_amd import scenarios  # noqa: E402
-from sccav_cbf_amd.batched import BatchedCBF, BatchTable, planes_to_tiled  # noqa: E402
+from sccav_cbf_amd.batched import BatchedCBF, BatchTable, planes_to_agents, planes_to_tiled  # noqa: E402
 
 
 def main():
@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--reps", type=int, default=300)
     ap.add_argument("--slots", default="prepared")
     ap.add_argument("--ks", default="1,2,4,8,10,16,20")
+    ap.add_argument("--layout", default="tiles", choices=("tiles", "agents", "planes"))
     args = ap.parse_args()
     dt = torch.float32 if args.dtype == "f32" else torch.float64
     w = 4 if args.dtype == "f32" else 8
@@ -40,7 +41,8 @@ def main():
         sh = 64 * 131 * (b + 1)
         ring.append(dict(state=torch.from_numpy(np.roll(base["state"], sh, axis=0)).to(dev).to(dt),
                          u_ref=torch.from_numpy(np.roll(base["u_ref"], sh, axis=0)).to(dev).to(dt),
-                         obs=planes_to_tiled(torch.from_numpy(np.roll(base["obs"], sh, axis=2)).to(dev).to(dt)),
+                         obs={"tiles": planes_to_tiled, "agents": planes_to_agents, "planes": lambda o: o.contiguous()}[args.layout](
+                             torch.from_numpy(np.roll(base["obs"], sh, axis=2)).to(dev).to(dt)),
                          obs_type=torch.from_numpy(base["obs_type"]).to(dev)))
     flt = BatchedCBF(alpha=1.0, R=np.diag([0.5, 0.5]), lanes_per_qp=args.lanes, streamed_obs=True)
     table = BatchTable(ring)

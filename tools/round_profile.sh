@@ -39,3 +39,9 @@ for L in agents tiles; do
 done
 LAYOUT=agents bash tools/prof_rows_pmc.sh 128 257 1024
 LAYOUT=tiles bash tools/prof_rows_pmc.sh 128 257 1024
+# long lists with ten independent batches per launch (sccbf_solve_batches_f32) against one launch per batch
+: > gpurun_out/r3_rows_fused.txt
+for R in 64 128 257 512; do for L in tiles agents; do
+  echo "== $R rows, layout $L" >> gpurun_out/r3_rows_fused.txt
+  timeout -k 10 300 python -u tools/bench_batches.py --ks 1,10 --ring 10 --reps 30 --rows $R --layout $L 2>&1 | grep "batches per launch" >> gpurun_out/r3_rows_fused.txt
+done; done
