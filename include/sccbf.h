@@ -114,10 +114,11 @@ extern "C" {
                                           the 8 scalars from obs + (a M + m) 8 on), the layout of a per-agent obstacle
                                           list.  The layout for long lists: the kernels for more than 128 rows
                                           give a workgroup a few agents, whose slots are then one contiguous
-                                          stream (at 257 ... 1024 rows a quarter faster than from tiles or planes,
-                                          where eight agents share every 128-byte line).  Accepted wherever
-                                          SCCBF_FLAG_OBS_TILED is; at most one of SCCBF_FLAG_OBS_SHARED, _TILED and
-                                          _AGENT_MAJOR.  For lists of up to 128 rows tiles are the faster layout */
+                                          stream (65536 agents, fp32: 5 % faster than from tiles at 257 rows, 8 % at
+                                          512, 21 % at 1024; from tiles or planes eight agents share every 128-byte
+                                          line).  Accepted wherever SCCBF_FLAG_OBS_TILED is; at most one of
+                                          SCCBF_FLAG_OBS_SHARED, _TILED and _AGENT_MAJOR.  For lists of up to 64 rows
+                                          tiles are the faster layout (12 % at 16 rows) */
 #define SCCBF_FLAG_CONE_BETA_STATE 16u /* sccbf_solve_sa_* only: every cone slot takes beta from the
                                           agent's slip state instead of its own o[5], which is what
                                           the reference's cones hold after SADBM's first solve
